@@ -1,0 +1,256 @@
+"""Procedural scene construction on flat tables (host side, numpy).
+
+Mirrors the reference's procedural helpers so that scenes built here are bit-identical to
+what the reference's C++ would build from the same arguments:
+
+  * ``add_quad_triangles``  -> /root/reference/src/objects/primatives/triangle.h:232-241
+  * ``add_box_triangles``   -> /root/reference/src/objects/primatives/triangle.h:243-309
+  * ``add_uv_sphere``       -> /root/reference/src/scene/scene_loader.h:204-242
+  * light duplication rule  -> /root/reference/src/scene/scene_loader.h:190-202
+
+A scene is a :class:`FlatScene`: triangle soup (N x 9 float64), per-triangle material index,
+a material table, the ordered list of emissive triangle ids (the reference's ``lights``
+collection) and the public camera fields of /root/reference/src/camera.h:26-41.
+"""
+from __future__ import annotations
+
+import math
+import struct
+from dataclasses import dataclass, field
+from typing import List, Sequence
+
+import numpy as np
+
+LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT = 0, 1, 2, 3
+
+# /root/reference/src/main.h:20
+PI = 3.1415926535897932385
+
+
+@dataclass
+class Material:
+    type: int
+    rgb: Sequence[float] = (0.0, 0.0, 0.0)
+    fuzz: float = 0.0
+    ior: float = 1.5
+
+
+@dataclass
+class Camera:
+    """Public camera fields (/root/reference/src/camera.h:26-41) with the reference's defaults."""
+    aspect_ratio: float = 1.0
+    image_width: int = 100
+    samples_per_pixel: int = 50
+    max_depth: int = 10
+    background: Sequence[float] = (0.0, 0.0, 0.0)
+    vfov: float = 90.0
+    lookfrom: Sequence[float] = (0.0, 0.0, 0.0)
+    lookat: Sequence[float] = (0.0, 0.0, -1.0)
+    vup: Sequence[float] = (0.0, 1.0, 0.0)
+    defocus_angle: float = 0.0
+    focus_dist: float = 10.0
+    file_name: str = "image.png"
+
+
+@dataclass
+class FlatScene:
+    materials: List[Material] = field(default_factory=list)
+    vertices: List[List[float]] = field(default_factory=list)     # 9 doubles per triangle
+    tri_material: List[int] = field(default_factory=list)
+    lights: List[int] = field(default_factory=list)
+    camera: Camera = field(default_factory=Camera)
+
+    # -- building -----------------------------------------------------------------
+    def add_material(self, m: Material) -> int:
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def add_triangle(self, v0, v1, v2, mat: int) -> None:
+        """world.add(tri); emissive triangles are also appended to the light list
+        (/root/reference/src/scene/scene_loader.h:190-202)."""
+        self.vertices.append([float(v0[0]), float(v0[1]), float(v0[2]),
+                              float(v1[0]), float(v1[1]), float(v1[2]),
+                              float(v2[0]), float(v2[1]), float(v2[2])])
+        self.tri_material.append(mat)
+        if self.materials[mat].type == DIFFUSE_LIGHT:
+            self.lights.append(len(self.tri_material) - 1)
+
+    # -- arrays for the C interfaces --------------------------------------------------
+    def vertex_array(self) -> np.ndarray:
+        return np.ascontiguousarray(np.array(self.vertices, dtype=np.float64).reshape(-1, 9))
+
+    def tri_material_array(self) -> np.ndarray:
+        return np.ascontiguousarray(np.array(self.tri_material, dtype=np.int32))
+
+    def light_array(self) -> np.ndarray:
+        return np.ascontiguousarray(np.array(self.lights, dtype=np.uint32))
+
+    def material_types(self) -> np.ndarray:
+        return np.ascontiguousarray(np.array([m.type for m in self.materials], dtype=np.int32))
+
+    def material_params(self) -> np.ndarray:
+        return np.ascontiguousarray(np.array(
+            [[m.rgb[0], m.rgb[1], m.rgb[2], m.fuzz, m.ior] for m in self.materials], dtype=np.float64))
+
+    @property
+    def n_triangles(self) -> int:
+        return len(self.tri_material)
+
+    # -- flat file consumed by the oracle tools (layout: oracle/flat_scene.h) ---------
+    def to_bytes(self) -> bytes:
+        out = [b"BDPTSCN1", struct.pack("<4I", len(self.materials), self.n_triangles, len(self.lights), 0)]
+        for m in self.materials:
+            out.append(struct.pack("<2i5d", m.type, 0, m.rgb[0], m.rgb[1], m.rgb[2], m.fuzz, m.ior))
+        for v, mat in zip(self.vertices, self.tri_material):
+            out.append(struct.pack("<9d2i", *v, mat, 0))
+        lights = list(self.lights) + ([0] if len(self.lights) % 2 else [])
+        out.append(struct.pack("<%dI" % len(lights), *lights))
+        c = self.camera
+        out.append(struct.pack("<16d4i", *c.lookfrom, *c.lookat, *c.vup, c.vfov, c.aspect_ratio, c.focus_dist,
+                               c.defocus_angle, *c.background, c.image_width, c.samples_per_pixel, c.max_depth, 0))
+        return b"".join(out)
+
+
+def _add(a, b):
+    return (a[0] + b[0], a[1] + b[1], a[2] + b[2])
+
+
+def add_quad_triangles(scene: FlatScene, q, u, v, mat: int) -> None:
+    """triangle.h:232-241: (q, q+u, q+v) and (q+u, q+u+v, q+v)."""
+    qu = _add(q, u)
+    qv = _add(q, v)
+    quv = _add(qu, v)           # (q + u) + v, the reference's association
+    scene.add_triangle(q, qu, qv, mat)
+    scene.add_triangle(qu, quv, qv, mat)
+
+
+def _rotate_y_point(p, sin_theta, cos_theta):
+    """triangle.h:243-249"""
+    return ((cos_theta * p[0]) + (sin_theta * p[2]), p[1], (-sin_theta * p[0]) + (cos_theta * p[2]))
+
+
+def add_box_triangles(scene: FlatScene, a, b, mat: int, rotate_y_degrees: float = 0.0, translate=(0.0, 0.0, 0.0)):
+    """triangle.h:251-309: 12 triangles, faces in the order +Z -Z -X +X +Y -Y."""
+    mn = (min(a[0], b[0]), min(a[1], b[1]), min(a[2], b[2]))
+    mx = (max(a[0], b[0]), max(a[1], b[1]), max(a[2], b[2]))
+    v000 = (mn[0], mn[1], mn[2]); v001 = (mn[0], mn[1], mx[2])
+    v010 = (mn[0], mx[1], mn[2]); v011 = (mn[0], mx[1], mx[2])
+    v100 = (mx[0], mn[1], mn[2]); v101 = (mx[0], mn[1], mx[2])
+    v110 = (mx[0], mx[1], mn[2]); v111 = (mx[0], mx[1], mx[2])
+    faces = [
+        (v001, v101, v111), (v001, v111, v011),
+        (v000, v010, v110), (v000, v110, v100),
+        (v000, v001, v011), (v000, v011, v010),
+        (v101, v100, v110), (v101, v110, v111),
+        (v011, v111, v110), (v011, v110, v010),
+        (v000, v100, v101), (v000, v101, v001),
+    ]
+    radians = rotate_y_degrees * PI / 180.0
+    sin_theta = math.sin(radians)
+    cos_theta = math.cos(radians)
+    for p0, p1, p2 in faces:
+        if rotate_y_degrees != 0.0:
+            p0 = _rotate_y_point(p0, sin_theta, cos_theta)
+            p1 = _rotate_y_point(p1, sin_theta, cos_theta)
+            p2 = _rotate_y_point(p2, sin_theta, cos_theta)
+        scene.add_triangle(_add(p0, translate), _add(p1, translate), _add(p2, translate), mat)
+
+
+def add_uv_sphere(scene: FlatScene, center, radius: float, mat: int, lat_steps: int = 16, lon_steps: int = 32):
+    """scene_loader.h:204-242 (its own literal of pi, scene_loader.h:221)."""
+    pi = 3.14159265358979323846
+
+    def sphere_point(theta, phi):
+        sin_theta = math.sin(theta)
+        x = radius * sin_theta * math.cos(phi)
+        y = radius * math.cos(theta)
+        z = radius * sin_theta * math.sin(phi)
+        return (center[0] + x, center[1] + y, center[2] + z)
+
+    for lat in range(lat_steps):
+        theta0 = pi * (float(lat) / lat_steps)
+        theta1 = pi * (float(lat + 1) / lat_steps)
+        for lon in range(lon_steps):
+            phi0 = 2.0 * pi * (float(lon) / lon_steps)
+            phi1 = 2.0 * pi * (float(lon + 1) / lon_steps)
+            p00 = sphere_point(theta0, phi0)
+            p01 = sphere_point(theta0, phi1)
+            p10 = sphere_point(theta1, phi0)
+            p11 = sphere_point(theta1, phi1)
+            if lat > 0:
+                scene.add_triangle(p00, p10, p11, mat)
+            if lat < lat_steps - 1:
+                scene.add_triangle(p00, p11, p01, mat)
+
+
+# ------------------------------------------------------------------------------- scenes
+def cornell_box(image_width: int = 512, samples_per_pixel: int = 256, max_depth: int = 10,
+                short_box: bool = False) -> FlatScene:
+    """Cornell geometry, materials and camera of /root/reference/src/main.cpp:17-33,42-53, with the
+    emissive ceiling quad itself as the light collection (the reference's own `lights` there carries
+    a null material and crashes in BDPT mode).  24 triangles; `short_box` adds the classic second
+    box (not in the reference) for 36."""
+    s = FlatScene()
+    red = s.add_material(Material(LAMBERTIAN, (.65, .05, .05)))
+    white = s.add_material(Material(LAMBERTIAN, (.73, .73, .73)))
+    green = s.add_material(Material(LAMBERTIAN, (.12, .45, .15)))
+    light = s.add_material(Material(DIFFUSE_LIGHT, (15.0, 15.0, 15.0)))
+    add_quad_triangles(s, (555, 0, 0), (0, 0, 555), (0, 555, 0), green)
+    add_quad_triangles(s, (0, 0, 555), (0, 0, -555), (0, 555, 0), red)
+    add_quad_triangles(s, (0, 555, 0), (555, 0, 0), (0, 0, 555), white)
+    add_quad_triangles(s, (0, 0, 555), (555, 0, 0), (0, 0, -555), white)
+    add_quad_triangles(s, (555, 0, 555), (-555, 0, 0), (0, 555, 0), white)
+    add_quad_triangles(s, (213, 554, 227), (130, 0, 0), (0, 0, 105), light)
+    add_box_triangles(s, (0, 0, 0), (165, 330, 165), white, 15.0, (265, 0, 295))
+    if short_box:
+        add_box_triangles(s, (0, 0, 0), (165, 165, 165), white, -18.0, (130, 0, 65))
+    s.camera = Camera(aspect_ratio=1.0, image_width=image_width, samples_per_pixel=samples_per_pixel,
+                      max_depth=max_depth, background=(0, 0, 0), vfov=40.0, lookfrom=(278, 278, -800),
+                      lookat=(278, 278, 0), vup=(0, 1, 0), defocus_angle=0.0, file_name="cornell_box.png")
+    return s
+
+
+def materials_showcase(image_width: int = 48, samples_per_pixel: int = 16, max_depth: int = 8) -> FlatScene:
+    """Small closed room that exercises every material branch of the hot path: lambertian walls,
+    a fuzzy metal box, a mirror (fuzz 0) floor, a dielectric box (ior 1.5) with a nested dielectric
+    (ior 1.33), an emissive quad and an emissive UV sphere (many light triangles), non-black
+    background seen through an open front."""
+    s = FlatScene()
+    white = s.add_material(Material(LAMBERTIAN, (.73, .73, .73)))
+    blue = s.add_material(Material(LAMBERTIAN, (.15, .25, .65)))
+    mirror = s.add_material(Material(METAL, (.9, .9, .9), fuzz=0.0))
+    brushed = s.add_material(Material(METAL, (.8, .6, .2), fuzz=0.3))
+    glass = s.add_material(Material(DIELECTRIC, ior=1.5))
+    water = s.add_material(Material(DIELECTRIC, ior=1.33))
+    light = s.add_material(Material(DIFFUSE_LIGHT, (12.0, 11.0, 9.0)))
+    glow = s.add_material(Material(DIFFUSE_LIGHT, (2.0, 3.0, 6.0)))
+    add_quad_triangles(s, (0, 0, 0), (10, 0, 0), (0, 0, 10), mirror)           # floor
+    add_quad_triangles(s, (0, 8, 0), (0, 0, 10), (10, 0, 0), white)            # ceiling
+    add_quad_triangles(s, (0, 0, 10), (10, 0, 0), (0, 8, 0), white)            # back
+    add_quad_triangles(s, (0, 0, 0), (0, 0, 10), (0, 8, 0), blue)              # left
+    add_quad_triangles(s, (10, 0, 0), (0, 8, 0), (0, 0, 10), white)            # right
+    add_quad_triangles(s, (3.5, 7.99, 3.5), (3, 0, 0), (0, 0, 3), light)       # ceiling light (faces down)
+    add_box_triangles(s, (0, 0, 0), (2, 4, 2), brushed, 20.0, (1.5, 0, 5.5))
+    add_box_triangles(s, (0, 0, 0), (2.5, 2.5, 2.5), glass, -15.0, (5.5, 0.01, 3.0))
+    add_box_triangles(s, (0, 0, 0), (1.5, 1.5, 1.5), water, -15.0, (6.0, 0.5, 3.6))
+    add_uv_sphere(s, (2.0, 5.5, 7.5), 0.8, glow, 6, 8)
+    s.camera = Camera(aspect_ratio=1.5, image_width=image_width, samples_per_pixel=samples_per_pixel,
+                      max_depth=max_depth, background=(0.05, 0.08, 0.12), vfov=55.0, lookfrom=(5, 4, -9),
+                      lookat=(5, 3.5, 5), vup=(0, 1, 0), defocus_angle=0.0, file_name="showcase.png")
+    return s
+
+
+def no_light_room(image_width: int = 24, samples_per_pixel: int = 4, max_depth: int = 5) -> FlatScene:
+    """Scene without any emissive material: `lights` falls back to the whole world
+    (/root/reference/src/main.cpp:67) and every light subpath dies after its three sampling
+    draws (/root/reference/src/camera.h:393-396); radiance comes from the background only."""
+    s = FlatScene()
+    grey = s.add_material(Material(LAMBERTIAN, (.5, .5, .5)))
+    metal = s.add_material(Material(METAL, (.7, .7, .7), fuzz=0.05))
+    add_quad_triangles(s, (-5, 0, -5), (10, 0, 0), (0, 0, 10), grey)
+    add_box_triangles(s, (-1, 0, -1), (1, 2, 1), metal, 30.0)
+    add_box_triangles(s, (2, 0, 1), (3, 1, 2), grey)
+    s.camera = Camera(aspect_ratio=1.0, image_width=image_width, samples_per_pixel=samples_per_pixel,
+                      max_depth=max_depth, background=(0.7, 0.8, 1.0), vfov=50.0, lookfrom=(0, 3, -8),
+                      lookat=(0, 1, 0), vup=(0, 1, 0), file_name="nolight.png")
+    return s

@@ -1,0 +1,359 @@
+// TEST INFRASTRUCTURE ONLY (oracle/_ref build).  Never shipped, never linked by the product.
+//
+// Drives the UNMODIFIED reference headers under /root/reference/src (compiled where
+// they lie, see oracle/Makefile) as a deterministic single-threaded oracle and dumps
+// what they compute, so that golden vectors can be committed under tests/golden/.
+//
+// The per-pixel loop below is the worker loop of camera::render (src/camera.h:116-124)
+// run on one thread; everything it calls (get_ray, ray_color -> bidirectional_color,
+// bvh_node::hit, materials ...) is the reference's own code.
+//
+// Build variants:
+//   default           : src/main.h is pre-empted by main_shim.h (re-seedable RNG streams)
+//   -DHARNESS_NO_SHIM : the real src/main.h is used (process-global mt19937); only the
+//                       `render_serial` / `rand` operations make sense then.
+
+// Standard headers first, so that the `private` -> `public` trick below cannot touch them.
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+#include <csetjmp>
+#include <png.h>
+
+#include "../flat_scene.h"
+
+#define private public
+#ifdef HARNESS_NO_SHIM
+#include "main.h"
+#else
+#include "main_shim.h"
+#endif
+#include "bvh.h"
+#include "camera.h"
+#include "hittable.h"
+#include "material.h"
+#include "triangle.h"
+#include "texture.h"
+#undef private
+
+static std::shared_ptr<material> make_material(const fs_material& m) {
+    color c(m.rgb[0], m.rgb[1], m.rgb[2]);
+    switch (m.type) {
+        case 0: return std::make_shared<lambertian>(c);
+        case 1: return std::make_shared<metal>(c, m.fuzz);
+        case 2: return std::make_shared<dielectric>(m.ior);
+        case 3: return std::make_shared<diffuse_light>(c);
+    }
+    fprintf(stderr, "bad material type %d\n", m.type);
+    exit(2);
+}
+
+struct built_scene {
+    triangle_collection world;
+    triangle_collection lights;
+    std::vector<std::shared_ptr<material>> mats;
+    std::shared_ptr<bvh_node> bvh;
+    std::vector<std::shared_ptr<hittable>> leaf_ptrs;   // world triangle i -> the heap copy the BVH holds
+    camera cam;
+};
+
+static point3 P(const double* v) { return point3(v[0], v[1], v[2]); }
+
+// unique_materials: give every triangle its own material object so that a hit_record's
+// `mat` pointer identifies the triangle that was hit (used only by the `hits` operation;
+// material values do not take part in intersection).
+static void build(const fs_scene& fs, built_scene& b, bool unique_materials) {
+    for (uint32_t i = 0; i < fs.n_materials; i++) b.mats.push_back(make_material(fs.materials[i]));
+    std::vector<std::shared_ptr<material>> tri_mats;
+    for (uint32_t i = 0; i < fs.n_triangles; i++) {
+        const fs_triangle& t = fs.triangles[i];
+        std::shared_ptr<material> m = unique_materials ? make_material(fs.materials[t.material]) : b.mats[t.material];
+        tri_mats.push_back(m);
+        b.world.add(triangle(P(t.v0), P(t.v1), P(t.v2), m));
+    }
+    for (uint32_t i = 0; i < fs.n_lights; i++) {
+        const fs_triangle& t = fs.triangles[fs.lights[i]];
+        b.lights.add(triangle(P(t.v0), P(t.v1), P(t.v2), tri_mats[fs.lights[i]]));
+    }
+    // src/main.cpp:66 : bvh_node(world.to_hittable_list())
+    hittable_list list = b.world.to_hittable_list();
+    b.leaf_ptrs = list.objects;
+    if (fs.n_triangles > 0) b.bvh = std::make_shared<bvh_node>(list);
+
+    const fs_camera& c = fs.camera;
+    b.cam.aspect_ratio = c.aspect_ratio;
+    b.cam.image_width = c.image_width;
+    b.cam.samples_per_pixel = c.samples_per_pixel;
+    b.cam.max_depth = c.max_depth;
+    b.cam.background = color(c.background[0], c.background[1], c.background[2]);
+    b.cam.vfov = c.vfov;
+    b.cam.lookfrom = P(c.lookfrom);
+    b.cam.lookat = P(c.lookat);
+    b.cam.vup = P(c.vup);
+    b.cam.defocus_angle = c.defocus_angle;
+    b.cam.focus_dist = c.focus_dist;
+}
+
+static void write_file(const char* path, const void* data, size_t bytes) {
+    FILE* f = fopen(path, "wb");
+    if (!f || fwrite(data, 1, bytes, f) != bytes) { fprintf(stderr, "cannot write %s\n", path); exit(3); }
+    fclose(f);
+}
+
+static std::vector<double> read_doubles(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "cannot read %s\n", path); exit(3); }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<double> v(n / 8);
+    if (fread(v.data(), 8, v.size(), f) != v.size()) exit(3);
+    fclose(f);
+    return v;
+}
+
+static void push_stats(std::vector<double>& out) {
+    auto& s = bvh_stats();
+    out.push_back((double)s.rays_traced.load());
+    out.push_back((double)s.aabb_tests.load());
+    out.push_back((double)s.aabb_hits.load());
+    out.push_back((double)s.bvh_node_visits.load());
+    out.push_back((double)s.triangle_tests.load());
+    out.push_back((double)s.triangle_hits.load());
+    out.push_back((double)s.bvh_nodes_built.load());
+}
+
+// DFS (left then right) over the reference tree: leaf triangle ids in visiting order and
+// every bvh_node's box in pre-order.
+static void walk(const hittable* h, const std::map<const hittable*, uint32_t>& ids,
+                 std::vector<double>& leaves, std::vector<double>& boxes) {
+    if (const bvh_node* n = dynamic_cast<const bvh_node*>(h)) {
+        boxes.push_back(n->bbox.x.min); boxes.push_back(n->bbox.x.max);
+        boxes.push_back(n->bbox.y.min); boxes.push_back(n->bbox.y.max);
+        boxes.push_back(n->bbox.z.min); boxes.push_back(n->bbox.z.max);
+        walk(n->left.get(), ids, leaves, boxes);
+        walk(n->right.get(), ids, leaves, boxes);
+    } else {
+        leaves.push_back((double)ids.at(h));
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        fprintf(stderr, "usage: ref_harness scene.bin op [args]\n");
+        return 1;
+    }
+    const std::string op = argv[2];
+
+#ifndef HARNESS_NO_SHIM
+    if (op == "rand") {   // first N doubles of the serial default-seeded engine (src/main.h:28-32 behaviour)
+        int n = atoi(argv[3]);
+        harness_rng().engine = 1;
+        std::vector<double> out;
+        for (int i = 0; i < n; i++) out.push_back(random_double());
+        write_file(argv[4], out.data(), out.size() * 8);
+        return 0;
+    }
+#else
+    if (op == "rand") {
+        int n = atoi(argv[3]);
+        std::vector<double> out;
+        for (int i = 0; i < n; i++) out.push_back(random_double());
+        write_file(argv[4], out.data(), out.size() * 8);
+        return 0;
+    }
+#endif
+
+    fs_scene fs;
+    if (fs_load(argv[1], &fs) != 0) { fprintf(stderr, "bad scene file\n"); return 2; }
+
+    built_scene b;
+    build(fs, b, op == "hits");
+    camera& cam = b.cam;
+    cam.initialize();
+    // src/main.cpp:67
+    const triangle_collection& lights = b.lights.empty() ? b.world : b.lights;
+
+    if (op == "camera") {
+        std::vector<double> o;
+        for (int k = 0; k < 3; k++) o.push_back(cam.center[k]);
+        for (int k = 0; k < 3; k++) o.push_back(cam.pixel00_loc[k]);
+        for (int k = 0; k < 3; k++) o.push_back(cam.pixel_delta_u[k]);
+        for (int k = 0; k < 3; k++) o.push_back(cam.pixel_delta_v[k]);
+        o.push_back(cam.image_height);
+        o.push_back(cam.sqrt_spp);
+        write_file(argv[3], o.data(), o.size() * 8);
+        return 0;
+    }
+
+    if (op == "dfs") {   // argv[3] leaves.bin  argv[4] boxes.bin
+        std::map<const hittable*, uint32_t> ids;
+        for (uint32_t i = 0; i < b.leaf_ptrs.size(); i++) ids[b.leaf_ptrs[i].get()] = i;
+        std::vector<double> leaves, boxes;
+        walk(b.bvh.get(), ids, leaves, boxes);
+        write_file(argv[3], leaves.data(), leaves.size() * 8);
+        write_file(argv[4], boxes.data(), boxes.size() * 8);
+        return 0;
+    }
+
+    if (op == "triangles") {  // precomputed per-triangle data of src/objects/primatives/triangle.h:21-39
+        std::vector<double> o;
+        for (const auto& t : b.world.tris) {
+            for (int k = 0; k < 3; k++) o.push_back(t.edge1[k]);
+            for (int k = 0; k < 3; k++) o.push_back(t.edge2[k]);
+            for (int k = 0; k < 3; k++) o.push_back(t.normal[k]);
+            o.push_back(t.area);
+            o.push_back(t.bbox.x.min); o.push_back(t.bbox.x.max);
+            o.push_back(t.bbox.y.min); o.push_back(t.bbox.y.max);
+            o.push_back(t.bbox.z.min); o.push_back(t.bbox.z.max);
+        }
+        write_file(argv[3], o.data(), o.size() * 8);
+        return 0;
+    }
+
+    if (op == "hits") {   // argv[3] rays.bin (o[3] d[3] tmin tmax)*  argv[4] out.bin
+        std::map<const material*, uint32_t> by_mat;
+        for (uint32_t i = 0; i < b.world.tris.size(); i++) by_mat[b.world.tris[i].mat.get()] = i;
+        std::vector<double> rays = read_doubles(argv[3]);
+        size_t n = rays.size() / 8;
+        std::vector<double> out;
+        out.reserve(n * 12);
+        reset_bvh_stats();
+        for (size_t i = 0; i < n; i++) {
+            const double* r = &rays[i * 8];
+            ray rr(point3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]), 0.0);
+            hit_record rec;
+            bool h = b.bvh->hit(rr, interval(r[6], r[7]), rec);
+            if (!h) {
+                out.push_back(-1.0);
+                for (int k = 0; k < 10; k++) out.push_back(0.0);
+            } else {
+                out.push_back((double)by_mat.at(rec.mat.get()));
+                out.push_back(rec.t); out.push_back(rec.u); out.push_back(rec.v);
+                out.push_back(rec.front_face ? 1.0 : 0.0);
+                for (int k = 0; k < 3; k++) out.push_back(rec.p[k]);
+                for (int k = 0; k < 3; k++) out.push_back(rec.normal[k]);
+            }
+        }
+        std::vector<double> st;
+        push_stats(st);
+        write_file(argv[4], out.data(), out.size() * 8);
+        if (argc > 5) write_file(argv[5], st.data(), st.size() * 8);
+        return 0;
+    }
+
+    if (op == "visible") {   // argv[3] pairs.bin (a[3] b[3])*  argv[4] out.bin
+        std::vector<double> pairs = read_doubles(argv[3]);
+        size_t n = pairs.size() / 6;
+        std::vector<double> out;
+        for (size_t i = 0; i < n; i++) {
+            const double* p = &pairs[i * 6];
+            out.push_back(cam.visible(point3(p[0], p[1], p[2]), point3(p[3], p[4], p[5]), *b.bvh) ? 1.0 : 0.0);
+        }
+        write_file(argv[4], out.data(), out.size() * 8);
+        return 0;
+    }
+
+    if (op == "rgb8") {   // argv[3] fb.bin  W H spp  out.bin   (src/image/wpng.h:14-35)
+        std::vector<double> fbd = read_doubles(argv[3]);
+        int W = atoi(argv[4]), H = atoi(argv[5]), spp = atoi(argv[6]);
+        std::vector<color> fb(size_t(W) * H);
+        for (size_t i = 0; i < fb.size(); i++) fb[i] = color(fbd[3 * i], fbd[3 * i + 1], fbd[3 * i + 2]);
+        std::vector<uint8_t> rgb;
+        colors_to_rgb8(fb, W, H, spp, rgb);
+        write_file(argv[7], rgb.data(), rgb.size());
+        return 0;
+    }
+
+#ifndef HARNESS_NO_SHIM
+    if (op == "render" || op == "samples") {
+        // argv: seed x0 y0 x1 y1 out.bin [stats.bin]
+        uint64_t seed = strtoull(argv[3], nullptr, 10);
+        int x0 = atoi(argv[4]), y0 = atoi(argv[5]), x1 = atoi(argv[6]), y1 = atoi(argv[7]);
+        const int W = cam.image_width;
+        const bool per_sample = (op == "samples");
+        std::vector<double> out;
+        reset_bvh_stats();
+        harness_rng().engine = 0;
+        harness_rng().total_draws = 0;
+        for (int j = y0; j < y1; j++) {
+            for (int i = x0; i < x1; i++) {
+                color pixel_color(0, 0, 0);
+                for (int s_j = 0; s_j < cam.sqrt_spp; s_j++) {
+                    for (int s_i = 0; s_i < cam.sqrt_spp; s_i++) {
+                        harness_rng().stream.key =
+                            orng_stream_key(seed, (uint64_t)j * W + i, (uint64_t)s_j * cam.sqrt_spp + s_i);
+                        harness_rng().stream.counter = 0;
+                        ray r = cam.get_ray(i, j, s_i, s_j);
+                        color c = cam.ray_color(r, cam.max_depth, *b.bvh, lights);
+                        pixel_color += c;
+                        if (per_sample) {
+                            out.push_back(c[0]); out.push_back(c[1]); out.push_back(c[2]);
+                            out.push_back((double)harness_rng().stream.counter);
+                        }
+                    }
+                }
+                if (!per_sample) { out.push_back(pixel_color[0]); out.push_back(pixel_color[1]); out.push_back(pixel_color[2]); }
+            }
+        }
+        write_file(argv[8], out.data(), out.size() * 8);
+        if (argc > 9) {
+            std::vector<double> st;
+            push_stats(st);
+            st.push_back((double)harness_rng().total_draws);
+            write_file(argv[9], st.data(), st.size() * 8);
+        }
+        return 0;
+    }
+#endif
+
+    if (op == "render_serial") {   // the reference's own global serial RNG; argv[3] out.bin
+#ifndef HARNESS_NO_SHIM
+        harness_rng().engine = 1;
+#endif
+        const int W = cam.image_width, H = cam.image_height;
+        std::vector<double> out;
+        reset_bvh_stats();
+        for (int j = 0; j < H; j++)
+            for (int i = 0; i < W; i++) {
+                color pixel_color(0, 0, 0);
+                for (int s_j = 0; s_j < cam.sqrt_spp; s_j++)
+                    for (int s_i = 0; s_i < cam.sqrt_spp; s_i++) {
+                        ray r = cam.get_ray(i, j, s_i, s_j);
+                        pixel_color += cam.ray_color(r, cam.max_depth, *b.bvh, lights);
+                    }
+                out.push_back(pixel_color[0]); out.push_back(pixel_color[1]); out.push_back(pixel_color[2]);
+            }
+        write_file(argv[3], out.data(), out.size() * 8);
+        if (argc > 4) {
+            std::vector<double> st;
+            push_stats(st);
+            write_file(argv[4], st.data(), st.size() * 8);
+        }
+        return 0;
+    }
+
+    fprintf(stderr, "unknown op %s\n", op.c_str());
+    return 1;
+}

@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ by running the reference's own headers.
+
+Needs /root/reference and the harness binaries of `make -C oracle ref` (oracle/_ref/), so it only
+runs in the build container; the GPU box and the CPU test-suite consume the committed .npz files.
+
+    python tests/golden/make_golden.py
+
+Every fixture is (inputs, outputs-of-the-reference).  Scenes are rebuilt by the tests from
+bidirectional-path-tracer_amd/scenes.py; the scene bytes are stored too so a drift in the scene
+builders is detected instead of silently changing the inputs.
+"""
+import hashlib
+import importlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+scenes = importlib.import_module("bidirectional-path-tracer_amd.scenes")
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+HARNESS = os.path.join(REF, "ref_harness")
+HARNESS_GLIBC = os.path.join(REF, "ref_harness_glibc")
+HARNESS_NOSHIM = os.path.join(REF, "ref_harness_noshim")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def run(binary, scene_path, *args):
+    subprocess.run([binary, scene_path, *[str(a) for a in args]], check=True)
+
+
+def rd(path, dtype=np.float64):
+    return np.fromfile(path, dtype=dtype)
+
+
+def scene_box(scene):
+    v = scene.vertex_array().reshape(-1, 3)
+    return v.min(axis=0), v.max(axis=0)
+
+
+def make_rays(scene, cam_desc, n, rng):
+    """A mix of rays: camera rays, rays between random points of the scene box, axis-aligned
+    rays (zero direction components -> infinities in the slab test), rays starting on surfaces."""
+    lo, hi = scene_box(scene)
+    ext = hi - lo
+    rays = np.zeros((n, 8))
+    center, p00, du, dv = cam_desc[0:3], cam_desc[3:6], cam_desc[6:9], cam_desc[9:12]
+    W = scene.camera.image_width
+    for k in range(n):
+        kind = k % 4
+        if kind == 0:      # camera ray through a random sub-pixel position
+            i, j = rng.uniform(0, W), rng.uniform(0, W)
+            o = center
+            d = p00 + i * du + j * dv - center
+        elif kind == 1:    # random segment inside the (slightly enlarged) scene box
+            o = lo - 0.05 * ext + rng.uniform(0, 1, 3) * 1.1 * ext
+            d = lo + rng.uniform(0, 1, 3) * ext - o
+        elif kind == 2:    # axis-aligned direction, origin inside the box
+            o = lo + rng.uniform(0.05, 0.95, 3) * ext
+            d = np.zeros(3)
+            d[rng.integers(0, 3)] = rng.choice([-1.0, 1.0]) * rng.uniform(0.5, 2.0)
+        else:              # unit direction from a point on a random triangle (offset like a bounce ray)
+            t = scene.vertex_array()[rng.integers(0, scene.n_triangles)].reshape(3, 3)
+            a, b = rng.uniform(0, 1, 2)
+            if a + b > 1:
+                a, b = 1 - a, 1 - b
+            o = t[0] + a * (t[1] - t[0]) + b * (t[2] - t[0])
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+        rays[k, 0:3] = o
+        rays[k, 3:6] = d
+        rays[k, 6] = 0.001
+        rays[k, 7] = np.inf if kind != 1 else rng.choice([np.inf, 1.0, 0.5])
+    return rays
+
+
+def surface_pairs(hits, n, rng):
+    """Visibility queries between surface points found by the hits fixture: exactly the
+    endpoint-on-surface situation of camera::visible."""
+    pts = hits[hits[:, 0] >= 0][:, 5:8]
+    a = pts[rng.integers(0, len(pts), n)]
+    b = pts[rng.integers(0, len(pts), n)]
+    return np.concatenate([a, b], axis=1)
+
+
+def golden_for(name, scene, tmp, *, seed, n_rays=0, n_pairs=0, crop=None, sample_crop=None, glibc=False):
+    spath = os.path.join(tmp, name + ".scene")
+    blob = scene.to_bytes()
+    with open(spath, "wb") as f:
+        f.write(blob)
+    g = {"scene_sha256": np.frombuffer(hashlib.sha256(blob).digest(), dtype=np.uint8)}
+    o = lambda s: os.path.join(tmp, name + "." + s)
+
+    run(HARNESS, spath, "camera", o("cam"))
+    cam = rd(o("cam"))
+    g["camera"] = cam
+    run(HARNESS, spath, "dfs", o("leaves"), o("boxes"))
+    g["dfs_leaves"] = rd(o("leaves")).astype(np.uint32)
+    g["node_boxes"] = rd(o("boxes")).reshape(-1, 6)
+    run(HARNESS, spath, "triangles", o("tris"))
+    g["triangle_data"] = rd(o("tris")).reshape(-1, 16)
+
+    rng = np.random.default_rng(seed)
+    if n_rays:
+        rays = make_rays(scene, cam, n_rays, rng)
+        rays.tofile(o("rays"))
+        run(HARNESS, spath, "hits", o("rays"), o("hits"), o("hstats"))
+        g["rays"] = rays
+        g["hits"] = rd(o("hits")).reshape(-1, 11)
+        g["hits_stats"] = rd(o("hstats")).astype(np.uint64)
+        if n_pairs:
+            pairs = surface_pairs(g["hits"], n_pairs, rng)
+            pairs.tofile(o("pairs"))
+            run(HARNESS, spath, "visible", o("pairs"), o("vis"))
+            g["pairs"] = pairs
+            g["visible"] = rd(o("vis")).astype(np.uint8)
+
+    W = scene.camera.image_width
+    H = int(cam[12])
+    x0, y0, x1, y1 = crop if crop else (0, 0, W, H)
+    run(HARNESS, spath, "render", seed, x0, y0, x1, y1, o("fb"), o("rstats"))
+    g["render_seed"] = np.array([seed], dtype=np.uint64)
+    g["render_rect"] = np.array([x0, y0, x1, y1], dtype=np.int32)
+    g["framebuffer"] = rd(o("fb")).reshape(y1 - y0, x1 - x0, 3)
+    g["render_stats"] = rd(o("rstats")).astype(np.uint64)      # 7 BvhStats + total draws
+    if sample_crop:
+        sx0, sy0, sx1, sy1 = sample_crop
+        run(HARNESS, spath, "samples", seed, sx0, sy0, sx1, sy1, o("smp"))
+        g["sample_rect"] = np.array(sample_crop, dtype=np.int32)
+        g["samples"] = rd(o("smp")).reshape(-1, 4)               # r g b draws
+    if glibc:
+        run(HARNESS_GLIBC, spath, "render", seed, x0, y0, x1, y1, o("fbg"))
+        g["framebuffer_glibc_libm"] = rd(o("fbg")).reshape(y1 - y0, x1 - x0, 3)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **g)
+    print(name, "ok:", scene.n_triangles, "triangles,", len(g["node_boxes"]), "nodes")
+    return g, spath
+
+
+def main():
+    for b in (HARNESS, HARNESS_GLIBC, HARNESS_NOSHIM):
+        if not os.path.exists(b):
+            sys.exit("missing %s - run `make -C oracle ref` first" % b)
+    with tempfile.TemporaryDirectory() as tmp:
+        # config-2 geometry, small image
+        g, spath = golden_for("cornell24", scenes.cornell_box(48, 16, 10), tmp, seed=0, n_rays=2048, n_pairs=1024,
+                              sample_crop=(20, 20, 28, 28), glibc=True)
+        # colors_to_rgb8 on that framebuffer (src/image/wpng.h:14-35)
+        fb = g["framebuffer"]
+        fb.tofile(os.path.join(tmp, "fb.bin"))
+        run(HARNESS, spath, "rgb8", os.path.join(tmp, "fb.bin"), fb.shape[1], fb.shape[0], 16, os.path.join(tmp, "rgb"))
+        np.savez_compressed(os.path.join(OUT, "cornell24_rgb8.npz"), rgb8=rd(os.path.join(tmp, "rgb"), np.uint8),
+                            spp=np.array([16], dtype=np.int32))
+
+        golden_for("cornell36", scenes.cornell_box(32, 4, 10, short_box=True), tmp, seed=7, n_rays=1024, n_pairs=512)
+        golden_for("showcase", scenes.materials_showcase(48, 16, 8), tmp, seed=3, n_rays=2048, n_pairs=1024,
+                   sample_crop=(16, 8, 32, 24))
+        golden_for("nolight", scenes.no_light_room(24, 4, 5), tmp, seed=11, n_rays=512)
+        # depth / spp edge cases: depth 1 (emitter vertex only), depth 2, depth 12; spp 1, 2 (sqrt_spp 1), 5 (sqrt_spp 2)
+        golden_for("cornell_d1", scenes.cornell_box(16, 4, 1), tmp, seed=1)
+        golden_for("cornell_d2", scenes.cornell_box(16, 5, 2), tmp, seed=2)
+        golden_for("cornell_d12", scenes.cornell_box(16, 2, 12), tmp, seed=5, sample_crop=(0, 0, 16, 16))
+        golden_for("showcase_d20", scenes.materials_showcase(24, 4, 20), tmp, seed=9, sample_crop=(0, 0, 24, 16))
+
+        # the unshimmed reference (real src/main.h: one serial default-seeded mt19937)
+        sc = scenes.cornell_box(16, 4, 5)
+        spath = os.path.join(tmp, "serial.scene")
+        with open(spath, "wb") as f:
+            f.write(sc.to_bytes())
+        run(HARNESS_NOSHIM, spath, "render_serial", os.path.join(tmp, "sfb"), os.path.join(tmp, "sst"))
+        run(HARNESS_NOSHIM, spath, "rand", 64, os.path.join(tmp, "rand"))
+        run(HARNESS_NOSHIM, spath, "camera", os.path.join(tmp, "scam"))
+        np.savez_compressed(os.path.join(OUT, "serial_mt.npz"),
+                            framebuffer=rd(os.path.join(tmp, "sfb")).reshape(16, 16, 3),
+                            stats=rd(os.path.join(tmp, "sst")).astype(np.uint64),
+                            rand=rd(os.path.join(tmp, "rand")), camera=rd(os.path.join(tmp, "scam")),
+                            scene_sha256=np.frombuffer(hashlib.sha256(sc.to_bytes()).digest(), dtype=np.uint8))
+        print("serial_mt ok")
+
+    prov = {
+        "generator": "tests/golden/make_golden.py",
+        "reference": "teehee567/Bidirectional-Path-Tracer @ 2025-11-21 (headers compiled in place from /root/reference/src)",
+        "compiler": subprocess.run(["g++", "--version"], capture_output=True, text=True).stdout.splitlines()[0],
+        "flags": "-std=c++17 -O2 -ffp-contract=off -fno-builtin-sin -fno-builtin-cos -fno-builtin-pow -pthread",
+        "libc": subprocess.run(["ldd", "--version"], capture_output=True, text=True).stdout.splitlines()[0],
+        "libm": "sin/cos/pow(.,5) interposed by oracle/ref_harness/cr_libm.c (correctly rounded); "
+                "`framebuffer_glibc_libm` in cornell24.npz is the same render with glibc's own libm",
+        "rng": "per-(pixel,sample) counter streams, oracle/oracle_rng.h; serial_mt.npz uses the reference's own src/main.h",
+    }
+    with open(os.path.join(OUT, "PROVENANCE.json"), "w") as f:
+        json.dump(prov, f, indent=2)
+
+
+if __name__ == "__main__":
+    main()
