@@ -1,0 +1,278 @@
+"""ctypes binding of libbdpt_amd.so (the C ABI declared in include/bdpt_amd.h).
+
+There is no CPU fallback: if the library is missing or cannot be loaded this module raises,
+and every call that fails raises :class:`BdptError` with the library's own message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbdpt_amd.so")
+
+BDPT_RENDER_COUNT_STATS = 1
+
+
+class BdptError(RuntimeError):
+    pass
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("reserved", C.c_int32), ("rgb", C.c_double * 3), ("fuzz", C.c_double),
+                ("ior", C.c_double)]
+
+
+class CameraPublic(C.Structure):
+    _fields_ = [("lookfrom", C.c_double * 3), ("lookat", C.c_double * 3), ("vup", C.c_double * 3),
+                ("vfov", C.c_double), ("aspect_ratio", C.c_double), ("focus_dist", C.c_double),
+                ("defocus_angle", C.c_double), ("background", C.c_double * 3), ("image_width", C.c_int32),
+                ("samples_per_pixel", C.c_int32), ("max_depth", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CameraState(C.Structure):
+    _fields_ = [("center", C.c_double * 3), ("pixel00_loc", C.c_double * 3), ("pixel_delta_u", C.c_double * 3),
+                ("pixel_delta_v", C.c_double * 3), ("background", C.c_double * 3), ("image_width", C.c_int32),
+                ("image_height", C.c_int32), ("sqrt_spp", C.c_int32), ("max_depth", C.c_int32)]
+
+    def as_array(self) -> np.ndarray:
+        """center pixel00 du dv background as 15 doubles (the layout the oracle takes)."""
+        return np.array([*self.center, *self.pixel00_loc, *self.pixel_delta_u, *self.pixel_delta_v, *self.background])
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32),
+                ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("shard_rows", C.c_int32), ("flags", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays_traced", "aabb_tests", "aabb_hits", "bvh_node_visits", "triangle_tests",
+                                          "triangle_hits", "shadow_rays", "connection_pairs", "rng_draws", "samples")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("n_triangles", C.c_uint32), ("n_materials", C.c_uint32), ("n_lights", C.c_uint32),
+                ("n_nodes", C.c_uint32), ("max_depth", C.c_uint32), ("reserved", C.c_uint32),
+                ("device_bytes", C.c_uint64)]
+
+
+# every symbol include/bdpt_amd.h declares
+EXPORTED_SYMBOLS = [
+    "bdpt_last_error", "bdpt_context_create", "bdpt_context_destroy", "bdpt_camera_initialize", "bdpt_scene_create",
+    "bdpt_scene_destroy", "bdpt_scene_get_info", "bdpt_scene_dfs_leaves", "bdpt_scene_node_boxes", "bdpt_trace_closest",
+    "bdpt_trace_closest_device", "bdpt_visible", "bdpt_render", "bdpt_render_device", "bdpt_render_get_stats",
+    "bdpt_colors_to_rgb8", "bdpt_colors_to_rgb8_device", "bdpt_device_sincos", "bdpt_device_random_doubles",
+    "bdpt_device_arith",
+]
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BdptError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, dp, u64 = C.c_void_p, C.POINTER(C.c_double), C.c_uint64
+    lib.bdpt_last_error.restype = C.c_char_p
+    lib.bdpt_context_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.bdpt_context_destroy.argtypes = [vp]
+    lib.bdpt_camera_initialize.argtypes = [C.POINTER(CameraPublic), C.POINTER(CameraState)]
+    lib.bdpt_scene_create.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(Material), C.c_uint32, vp, C.c_uint32, C.POINTER(vp)]
+    lib.bdpt_scene_destroy.argtypes = [vp]
+    lib.bdpt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
+    lib.bdpt_scene_dfs_leaves.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.bdpt_scene_node_boxes.argtypes = [vp, vp, C.c_uint32]
+    lib.bdpt_trace_closest.argtypes = [vp, vp, vp, u64, vp, C.POINTER(Stats)]
+    lib.bdpt_trace_closest_device.argtypes = [vp, vp, vp, u64, vp, vp]
+    lib.bdpt_visible.argtypes = [vp, vp, vp, u64, vp]
+    lib.bdpt_render.argtypes = [vp, vp, C.POINTER(CameraState), C.POINTER(RenderParams), vp, C.POINTER(Stats)]
+    lib.bdpt_render_device.argtypes = [vp, vp, C.POINTER(CameraState), C.POINTER(RenderParams), vp, vp]
+    lib.bdpt_render_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.bdpt_colors_to_rgb8.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp]
+    lib.bdpt_colors_to_rgb8_device.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
+    lib.bdpt_device_sincos.argtypes = [vp, vp, u64, vp, vp]
+    lib.bdpt_device_random_doubles.argtypes = [vp, u64, u64, u64, u64, vp]
+    lib.bdpt_device_arith.argtypes = [vp, C.c_int, vp, vp, u64, vp]
+    for name in EXPORTED_SYMBOLS:
+        if name != "bdpt_last_error":
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise BdptError("bdpt error %d: %s" % (rc, load_library().bdpt_last_error().decode()))
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def camera_public_from(cam) -> CameraPublic:
+    """From a scenes.Camera (public fields of /root/reference/src/camera.h:26-41)."""
+    p = CameraPublic()
+    p.lookfrom[:] = [float(v) for v in cam.lookfrom]
+    p.lookat[:] = [float(v) for v in cam.lookat]
+    p.vup[:] = [float(v) for v in cam.vup]
+    p.vfov, p.aspect_ratio, p.focus_dist, p.defocus_angle = cam.vfov, cam.aspect_ratio, cam.focus_dist, cam.defocus_angle
+    p.background[:] = [float(v) for v in cam.background]
+    p.image_width, p.samples_per_pixel, p.max_depth = cam.image_width, cam.samples_per_pixel, cam.max_depth
+    return p
+
+
+def camera_initialize(cam) -> CameraState:
+    st = CameraState()
+    pub = cam if isinstance(cam, CameraPublic) else camera_public_from(cam)
+    _check(load_library().bdpt_camera_initialize(C.byref(pub), C.byref(st)))
+    return st
+
+
+def colors_to_rgb8(fb: np.ndarray, spp: int) -> np.ndarray:
+    fb = np.ascontiguousarray(fb, dtype=np.float64)
+    H, W = fb.shape[0], fb.shape[1]
+    out = np.zeros((H, W, 3), dtype=np.uint8)
+    _check(load_library().bdpt_colors_to_rgb8(_ptr(fb), W, H, spp, _ptr(out)))
+    return out
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib.bdpt_context_create(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bdpt_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    # -- test hooks ---------------------------------------------------------------
+    def device_sincos(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        s, c = np.zeros_like(x), np.zeros_like(x)
+        _check(self.lib.bdpt_device_sincos(self.h, _ptr(x), x.size, _ptr(s), _ptr(c)))
+        return s, c
+
+    def device_random_doubles(self, seed, pixel, sample, n):
+        o = np.zeros(n)
+        _check(self.lib.bdpt_device_random_doubles(self.h, seed, pixel, sample, n, _ptr(o)))
+        return o
+
+    def device_arith(self, op, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        o = np.zeros_like(a)
+        _check(self.lib.bdpt_device_arith(self.h, op, _ptr(a), _ptr(b), a.size, _ptr(o)))
+        return o
+
+    def scene(self, flat) -> "Scene":
+        return Scene(self, flat)
+
+
+class Scene:
+    """bdpt_scene built from a scenes.FlatScene."""
+
+    def __init__(self, ctx: Context, flat):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.flat = flat
+        v = flat.vertex_array()
+        tm = flat.tri_material_array()
+        mats = (Material * max(1, len(flat.materials)))()
+        for i, m in enumerate(flat.materials):
+            mats[i].type = m.type
+            mats[i].rgb[:] = [float(c) for c in m.rgb]
+            mats[i].fuzz = m.fuzz
+            mats[i].ior = m.ior
+        li = flat.light_array()
+        h = C.c_void_p()
+        _check(self.lib.bdpt_scene_create(ctx.h, _ptr(v), _ptr(tm), flat.n_triangles, mats, len(flat.materials),
+                                          _ptr(li) if len(li) else None, len(li), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.lib.bdpt_scene_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def info(self) -> SceneInfo:
+        i = SceneInfo()
+        _check(self.lib.bdpt_scene_get_info(self.h, C.byref(i)))
+        return i
+
+    def dfs_leaves(self) -> np.ndarray:
+        cap = 2 * self.flat.n_triangles + 4
+        out = np.zeros(cap, dtype=np.uint32)
+        n = C.c_uint32()
+        _check(self.lib.bdpt_scene_dfs_leaves(self.h, _ptr(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def node_boxes(self) -> np.ndarray:
+        n = self.info().n_nodes
+        out = np.zeros((n, 6))
+        _check(self.lib.bdpt_scene_node_boxes(self.h, _ptr(out), n))
+        return out
+
+    def trace_closest(self, rays, want_stats=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 8)
+        hits = np.zeros((len(rays), 11))
+        st = Stats()
+        _check(self.lib.bdpt_trace_closest(self.ctx.h, self.h, _ptr(rays), len(rays), _ptr(hits),
+                                           C.byref(st) if want_stats else None))
+        return (hits, st) if want_stats else hits
+
+    def visible(self, pairs):
+        pairs = np.ascontiguousarray(pairs, dtype=np.float64).reshape(-1, 6)
+        out = np.zeros(len(pairs), dtype=np.uint8)
+        _check(self.lib.bdpt_visible(self.ctx.h, self.h, _ptr(pairs), len(pairs), _ptr(out)))
+        return out
+
+    def render(self, cam_state: CameraState, seed=0, rect=None, shard=(0, 1, 1), want_stats=False, framebuffer=None):
+        """Host-buffer render; returns the full W x H x 3 framebuffer of sums (unowned pixels keep
+        the values of `framebuffer`, zeros by default) and optionally the counters."""
+        W, H = cam_state.image_width, cam_state.image_height
+        fb = np.zeros((H, W, 3)) if framebuffer is None else np.ascontiguousarray(framebuffer, dtype=np.float64)
+        p = RenderParams()
+        p.seed = seed
+        if rect is not None:
+            p.x0, p.y0, p.x1, p.y1 = [int(v) for v in rect]
+        p.shard_index, p.shard_count, p.shard_rows = shard
+        p.flags = BDPT_RENDER_COUNT_STATS if want_stats else 0
+        st = Stats()
+        _check(self.lib.bdpt_render(self.ctx.h, self.h, C.byref(cam_state), C.byref(p), _ptr(fb), C.byref(st)))
+        return (fb, st) if want_stats else fb
+
+    def render_device(self, cam_state: CameraState, d_framebuffer: int, seed=0, rect=None, shard=(0, 1, 1),
+                      want_stats=False, stream: int = 0):
+        """Framebuffer already in device memory (`d_framebuffer` = device pointer, e.g. tensor.data_ptr())."""
+        p = RenderParams()
+        p.seed = seed
+        if rect is not None:
+            p.x0, p.y0, p.x1, p.y1 = [int(v) for v in rect]
+        p.shard_index, p.shard_count, p.shard_rows = shard
+        p.flags = BDPT_RENDER_COUNT_STATS if want_stats else 0
+        _check(self.lib.bdpt_render_device(self.ctx.h, self.h, C.byref(cam_state), C.byref(p), C.c_void_p(d_framebuffer),
+                                           C.c_void_p(stream)))
+
+    def last_stats(self) -> Stats:
+        st = Stats()
+        _check(self.lib.bdpt_render_get_stats(self.ctx.h, C.byref(st)))
+        return st

@@ -1,0 +1,499 @@
+// C ABI (include/bdpt_amd.h) over the HIP kernels: contexts, scene upload, render / trace entry points.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/bdpt_amd.h"
+#include "bdpt_types.h"
+#include "kernels.h"
+#include "scene_build.h"
+
+using namespace bdpt;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(e == hipErrorOutOfMemory ? BDPT_ERR_OUT_OF_MEMORY : BDPT_ERR_DEVICE,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                             \
+    do {                                                          \
+        hipError_t _e = (expr);                                   \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);         \
+    } while (0)
+
+constexpr int kBlock = 256;
+constexpr int kStatWords = 10;
+
+}  // namespace
+
+struct bdpt_context {
+    int device = 0;
+    int cu_count = 0;
+    // reusable device buffers
+    double* vertex_ws = nullptr;
+    size_t vertex_ws_bytes = 0;
+    int32_t* rows = nullptr;
+    size_t rows_capacity = 0;
+    uint32_t* unit_counter = nullptr;
+    unsigned long long* stats = nullptr;
+    bool stats_valid = false;
+};
+
+struct bdpt_scene {
+    bdpt_context* ctx = nullptr;
+    HostScene host;
+    SceneDev dev{};
+    void* d_blob = nullptr;
+    size_t blob_bytes = 0;
+    uint32_t n_materials = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int ensure_rows(bdpt_context* ctx, size_t n) {
+    if (ctx->rows_capacity >= n) return BDPT_OK;
+    if (ctx->rows) (void)hipFree(ctx->rows);
+    ctx->rows = nullptr;
+    ctx->rows_capacity = 0;
+    HIP_TRY(hipMalloc(&ctx->rows, sizeof(int32_t) * n));
+    ctx->rows_capacity = n;
+    return BDPT_OK;
+}
+
+int ensure_vertex_ws(bdpt_context* ctx, size_t bytes) {
+    if (ctx->vertex_ws_bytes >= bytes) return BDPT_OK;
+    if (ctx->vertex_ws) (void)hipFree(ctx->vertex_ws);
+    ctx->vertex_ws = nullptr;
+    ctx->vertex_ws_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx->vertex_ws, bytes));
+    ctx->vertex_ws_bytes = bytes;
+    return BDPT_OK;
+}
+
+void read_stats(const unsigned long long* h, bdpt_stats* out) {
+    out->rays_traced = h[0]; out->aabb_tests = h[1]; out->aabb_hits = h[2]; out->bvh_node_visits = h[3];
+    out->triangle_tests = h[4]; out->triangle_hits = h[5]; out->shadow_rays = h[6]; out->connection_pairs = h[7];
+    out->rng_draws = h[8]; out->samples = h[9];
+}
+
+GpuCamera to_gpu_camera(const bdpt_camera_state& c) {
+    GpuCamera g;
+    for (int k = 0; k < 3; k++) {
+        g.center[k] = c.center[k]; g.pixel00[k] = c.pixel00_loc[k]; g.du[k] = c.pixel_delta_u[k];
+        g.dv[k] = c.pixel_delta_v[k]; g.background[k] = c.background[k];
+    }
+    g.recip_sqrt_spp = 1.0 / c.sqrt_spp;        // camera.h:166
+    g.width = c.image_width; g.height = c.image_height; g.sqrt_spp = c.sqrt_spp; g.max_depth = c.max_depth;
+    return g;
+}
+
+int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, const bdpt_render_params* p,
+                double* d_fb, hipStream_t stream) {
+    if (!ctx || !scene || !cam || !p || !d_fb) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    if (scene->ctx != ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "scene belongs to another context");
+    if (cam->image_width <= 0 || cam->image_height <= 0) return fail(BDPT_ERR_INVALID_ARGUMENT, "empty image");
+    if (cam->sqrt_spp < 1) return fail(BDPT_ERR_INVALID_ARGUMENT, "sqrt_spp must be at least 1");
+    if (cam->max_depth < 0 || cam->max_depth > 4096) return fail(BDPT_ERR_INVALID_ARGUMENT, "max_depth out of range");
+    if ((int64_t)cam->sqrt_spp * cam->sqrt_spp > (1 << 24)) return fail(BDPT_ERR_INVALID_ARGUMENT, "too many samples per pixel");
+
+    const int W = cam->image_width, H = cam->image_height;
+    int x0 = p->x0 < 0 ? 0 : p->x0, y0 = p->y0 < 0 ? 0 : p->y0;
+    int x1 = (p->x1 <= 0 || p->x1 > W) ? W : p->x1;
+    int y1 = (p->y1 <= 0 || p->y1 > H) ? H : p->y1;
+    const int shard_count = p->shard_count <= 0 ? 1 : p->shard_count;
+    const int shard_rows = p->shard_rows <= 0 ? 1 : p->shard_rows;
+    if (p->shard_index < 0 || p->shard_index >= shard_count) return fail(BDPT_ERR_INVALID_ARGUMENT, "shard_index out of range");
+    const bool want_stats = (p->flags & BDPT_RENDER_COUNT_STATS) != 0;
+    ctx->stats_valid = false;
+    if (want_stats) HIP_TRY(hipMemsetAsync(ctx->stats, 0, sizeof(unsigned long long) * kStatWords, stream));
+    if (x0 >= x1 || y0 >= y1) { ctx->stats_valid = want_stats; return BDPT_OK; }
+
+    std::vector<int32_t> rows;
+    for (int j = y0; j < y1; j++)
+        if ((j / shard_rows) % shard_count == p->shard_index) rows.push_back(j);
+    if (rows.empty()) { ctx->stats_valid = want_stats; return BDPT_OK; }
+
+    int rc = ensure_rows(ctx, rows.size());
+    if (rc != BDPT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->rows, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));      // `rows` is a stack-lifetime host buffer
+    HIP_TRY(hipMemsetAsync(ctx->unit_counter, 0, sizeof(uint32_t), stream));
+
+    const int spp = cam->sqrt_spp * cam->sqrt_spp;
+    const int ppg = spp >= kBlock ? 1 : kBlock / spp;
+    const int64_t n_owned = (int64_t)rows.size() * (x1 - x0);
+    const int64_t n_units = (n_owned + ppg - 1) / ppg;
+    if (n_units > 0x7FFFFFFF) return fail(BDPT_ERR_INVALID_ARGUMENT, "too many work units in one call");
+
+    // persistent grid: enough workgroups to fill the chip, never more than there is work
+    int per_cu = 1;
+    HIP_TRY(render_blocks_per_cu(scene->dev, want_stats, &per_cu));
+    int64_t grid = (int64_t)ctx->cu_count * per_cu;
+    if (grid > n_units) grid = n_units;
+    const size_t ws_stride = (size_t)grid * kBlock;
+    const size_t slots = 2 * (size_t)(cam->max_depth > 0 ? cam->max_depth : 1);
+    rc = ensure_vertex_ws(ctx, align256(ws_stride * slots * 10 * sizeof(double)));
+    if (rc != BDPT_OK) return rc;
+
+    RenderLaunch rl;
+    rl.seed = p->seed;
+    rl.rows = ctx->rows;
+    rl.n_rows = (int32_t)rows.size();
+    rl.x0 = x0; rl.x1 = x1;
+    rl.pixels_per_group = ppg;
+    rl.n_units = (int32_t)n_units;
+    rl.unit_counter = ctx->unit_counter;
+    rl.fb = d_fb;
+    rl.vertex_ws = ctx->vertex_ws;
+    rl.stats = want_stats ? ctx->stats : nullptr;
+    rl.ws_stride = ws_stride;
+    HIP_TRY(launch_render(scene->dev, to_gpu_camera(*cam), rl, (int)grid, want_stats, stream));
+    ctx->stats_valid = want_stats;
+    return BDPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bdpt_last_error(void) { return g_last_error.c_str(); }
+
+int bdpt_context_create(int device_index, bdpt_context** out) {
+    if (!out) return fail(BDPT_ERR_INVALID_ARGUMENT, "null output pointer");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) return fail(BDPT_ERR_DEVICE, "no HIP device available");
+    if (device_index < 0 || device_index >= count) return fail(BDPT_ERR_INVALID_ARGUMENT, "device index out of range");
+    DeviceGuard guard(device_index);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_index));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(BDPT_ERR_UNSUPPORTED, std::string("built for gfx950 (MI355X), found ") + prop.gcnArchName);
+    bdpt_context* ctx = new (std::nothrow) bdpt_context();
+    if (!ctx) return fail(BDPT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ctx->device = device_index;
+    ctx->cu_count = prop.multiProcessorCount;
+    if (hipMalloc(&ctx->unit_counter, 256) != hipSuccess || hipMalloc(&ctx->stats, 256) != hipSuccess) {
+        bdpt_context_destroy(ctx);
+        return fail(BDPT_ERR_OUT_OF_MEMORY, "device allocation failed");
+    }
+    *out = ctx;
+    return BDPT_OK;
+}
+
+int bdpt_context_destroy(bdpt_context* ctx) {
+    if (!ctx) return BDPT_OK;
+    DeviceGuard guard(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->vertex_ws) (void)hipFree(ctx->vertex_ws);
+    if (ctx->rows) (void)hipFree(ctx->rows);
+    if (ctx->unit_counter) (void)hipFree(ctx->unit_counter);
+    if (ctx->stats) (void)hipFree(ctx->stats);
+    delete ctx;
+    return BDPT_OK;
+}
+
+int bdpt_camera_initialize(const bdpt_camera_public* cam, bdpt_camera_state* out) {
+    if (!cam || !out) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    std::string err = camera_initialize(*cam, *out);
+    if (!err.empty()) return fail(BDPT_ERR_INVALID_ARGUMENT, err);
+    return BDPT_OK;
+}
+
+int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32_t* tri_material, uint32_t n_triangles,
+                      const bdpt_material* materials, uint32_t n_materials, const uint32_t* light_triangles,
+                      uint32_t n_lights, bdpt_scene** out) {
+    if (!ctx || !out) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    bdpt_scene* s = new (std::nothrow) bdpt_scene();
+    if (!s) return fail(BDPT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    s->ctx = ctx;
+    s->n_materials = n_materials;
+    std::string err;
+    try {
+        err = build_host_scene(tri_vertices, tri_material, n_triangles, materials, n_materials, light_triangles, n_lights, s->host);
+    } catch (const std::bad_alloc&) {
+        delete s;
+        return fail(BDPT_ERR_OUT_OF_MEMORY, "host allocation failed while building the scene");
+    }
+    if (!err.empty()) { delete s; return fail(BDPT_ERR_INVALID_ARGUMENT, err); }
+
+    const HostScene& h = s->host;
+    // one device allocation, tables at 256-byte aligned offsets
+    size_t off_nodes = 0;
+    size_t off_tris = off_nodes + align256(h.nodes.size() * sizeof(GpuNode));
+    size_t off_aux = off_tris + align256(h.tris.size() * sizeof(GpuTri));
+    size_t off_mats = off_aux + align256(h.aux.size() * sizeof(GpuTriAux));
+    size_t off_ltri = off_mats + align256(h.mats.size() * sizeof(GpuMaterial));
+    size_t off_lacc = off_ltri + align256(h.light_tris.size() * sizeof(uint32_t));
+    size_t total = off_lacc + align256(h.light_accum.size() * sizeof(double));
+    DeviceGuard guard(ctx->device);
+    hipError_t e = hipMalloc(&s->d_blob, total);
+    if (e != hipSuccess) { delete s; return hip_fail(e, "hipMalloc(scene)"); }
+    s->blob_bytes = total;
+    char* base = static_cast<char*>(s->d_blob);
+    struct { size_t off; const void* src; size_t bytes; } parts[] = {
+        {off_nodes, h.nodes.data(), h.nodes.size() * sizeof(GpuNode)},
+        {off_tris, h.tris.data(), h.tris.size() * sizeof(GpuTri)},
+        {off_aux, h.aux.data(), h.aux.size() * sizeof(GpuTriAux)},
+        {off_mats, h.mats.data(), h.mats.size() * sizeof(GpuMaterial)},
+        {off_ltri, h.light_tris.data(), h.light_tris.size() * sizeof(uint32_t)},
+        {off_lacc, h.light_accum.data(), h.light_accum.size() * sizeof(double)},
+    };
+    for (auto& p : parts) {
+        e = hipMemcpy(base + p.off, p.src, p.bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return hip_fail(e, "hipMemcpy(scene)"); }
+    }
+    SceneDev& d = s->dev;
+    d.nodes = reinterpret_cast<const GpuNode*>(base + off_nodes);
+    d.tris = reinterpret_cast<const GpuTri*>(base + off_tris);
+    d.aux = reinterpret_cast<const GpuTriAux*>(base + off_aux);
+    d.mats = reinterpret_cast<const GpuMaterial*>(base + off_mats);
+    d.light_tris = reinterpret_cast<const uint32_t*>(base + off_ltri);
+    d.light_accum = reinterpret_cast<const double*>(base + off_lacc);
+    d.light_total_area = h.light_total_area;
+    d.n_nodes = (uint32_t)h.nodes.size();
+    d.n_tris = (uint32_t)h.tris.size();
+    d.n_mats = (uint32_t)h.mats.size();
+    d.n_lights = (uint32_t)h.light_tris.size();
+    *out = s;
+    return BDPT_OK;
+}
+
+int bdpt_scene_destroy(bdpt_scene* scene) {
+    if (!scene) return BDPT_OK;
+    DeviceGuard guard(scene->ctx->device);
+    (void)hipDeviceSynchronize();
+    if (scene->d_blob) (void)hipFree(scene->d_blob);
+    delete scene;
+    return BDPT_OK;
+}
+
+int bdpt_scene_get_info(const bdpt_scene* scene, bdpt_scene_info* out) {
+    if (!scene || !out) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    out->n_triangles = scene->dev.n_tris;
+    out->n_materials = scene->dev.n_mats;
+    out->n_lights = scene->dev.n_lights;
+    out->n_nodes = scene->dev.n_nodes;
+    out->max_depth = scene->host.tree_depth;
+    out->reserved = 0;
+    out->device_bytes = scene->blob_bytes;
+    return BDPT_OK;
+}
+
+int bdpt_scene_dfs_leaves(const bdpt_scene* scene, uint32_t* out, uint32_t capacity, uint32_t* count) {
+    if (!scene || !count) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    const std::vector<uint32_t>& v = scene->host.dfs_leaves;
+    *count = (uint32_t)v.size();
+    if (out) for (uint32_t i = 0; i < v.size() && i < capacity; i++) out[i] = v[i];
+    return BDPT_OK;
+}
+
+int bdpt_scene_node_boxes(const bdpt_scene* scene, double* out, uint32_t capacity_nodes) {
+    if (!scene || !out) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    const std::vector<GpuNode>& n = scene->host.nodes;
+    if (capacity_nodes < n.size()) return fail(BDPT_ERR_INVALID_ARGUMENT, "output buffer too small");
+    for (size_t i = 0; i < n.size(); i++)
+        for (int k = 0; k < 3; k++) { out[6 * i + 2 * k] = n[i].lo[k]; out[6 * i + 2 * k + 1] = n[i].hi[k]; }
+    return BDPT_OK;
+}
+
+int bdpt_trace_closest_device(bdpt_context* ctx, const bdpt_scene* scene, const void* d_rays, uint64_t n, void* d_hits,
+                              void* stream) {
+    if (!ctx || !scene || (n && (!d_rays || !d_hits))) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    if (scene->ctx != ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "scene belongs to another context");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(launch_trace_closest(scene->dev, static_cast<const double*>(d_rays), n, static_cast<double*>(d_hits), nullptr,
+                                 static_cast<hipStream_t>(stream)));
+    return BDPT_OK;
+}
+
+int bdpt_trace_closest(bdpt_context* ctx, const bdpt_scene* scene, const double* rays, uint64_t n, double* hits,
+                       bdpt_stats* stats) {
+    if (!ctx || !scene || (n && (!rays || !hits))) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    if (scene->ctx != ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "scene belongs to another context");
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0) return BDPT_OK;
+    DeviceGuard guard(ctx->device);
+    double *d_rays = nullptr, *d_hits = nullptr;
+    HIP_TRY(hipMalloc(&d_rays, n * 8 * sizeof(double)));
+    hipError_t e = hipMalloc(&d_hits, n * 11 * sizeof(double));
+    if (e != hipSuccess) { (void)hipFree(d_rays); return hip_fail(e, "hipMalloc(hits)"); }
+    int rc = BDPT_OK;
+    do {
+        if ((e = hipMemcpy(d_rays, rays, n * 8 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
+        if (stats && (e = hipMemset(ctx->stats, 0, sizeof(unsigned long long) * kStatWords)) != hipSuccess) break;
+        if ((e = launch_trace_closest(scene->dev, d_rays, n, d_hits, stats ? ctx->stats : nullptr, nullptr)) != hipSuccess) break;
+        if ((e = hipMemcpy(hits, d_hits, n * 11 * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if (stats) {
+            unsigned long long h[kStatWords];
+            if ((e = hipMemcpy(h, ctx->stats, sizeof h, hipMemcpyDeviceToHost)) != hipSuccess) break;
+            read_stats(h, stats);
+        }
+    } while (0);
+    (void)hipFree(d_rays);
+    (void)hipFree(d_hits);
+    if (e != hipSuccess) rc = hip_fail(e, "bdpt_trace_closest");
+    return rc;
+}
+
+int bdpt_visible(bdpt_context* ctx, const bdpt_scene* scene, const double* pairs, uint64_t n, uint8_t* out) {
+    if (!ctx || !scene || (n && (!pairs || !out))) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    if (scene->ctx != ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "scene belongs to another context");
+    if (n == 0) return BDPT_OK;
+    DeviceGuard guard(ctx->device);
+    double* d_pairs = nullptr;
+    uint8_t* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_pairs, n * 6 * sizeof(double)));
+    hipError_t e = hipMalloc(&d_out, n);
+    if (e != hipSuccess) { (void)hipFree(d_pairs); return hip_fail(e, "hipMalloc(visible)"); }
+    do {
+        if ((e = hipMemcpy(d_pairs, pairs, n * 6 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = launch_visible(scene->dev, d_pairs, n, d_out, nullptr)) != hipSuccess) break;
+        if ((e = hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    } while (0);
+    (void)hipFree(d_pairs);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return hip_fail(e, "bdpt_visible");
+    return BDPT_OK;
+}
+
+int bdpt_render_device(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam,
+                       const bdpt_render_params* params, void* d_framebuffer, void* stream) {
+    if (!ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "null context");
+    DeviceGuard guard(ctx->device);
+    return render_impl(ctx, scene, cam, params, static_cast<double*>(d_framebuffer), static_cast<hipStream_t>(stream));
+}
+
+int bdpt_render_get_stats(bdpt_context* ctx, bdpt_stats* out) {
+    if (!ctx || !out) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->stats_valid) return fail(BDPT_ERR_INVALID_ARGUMENT, "the last render did not request BDPT_RENDER_COUNT_STATS");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h[kStatWords];
+    HIP_TRY(hipMemcpy(h, ctx->stats, sizeof h, hipMemcpyDeviceToHost));
+    read_stats(h, out);
+    return BDPT_OK;
+}
+
+int bdpt_render(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, const bdpt_render_params* params,
+                double* framebuffer, bdpt_stats* stats) {
+    if (!ctx || !cam || !framebuffer) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    if (cam->image_width <= 0 || cam->image_height <= 0) return fail(BDPT_ERR_INVALID_ARGUMENT, "empty image");
+    DeviceGuard guard(ctx->device);
+    const size_t bytes = (size_t)cam->image_width * cam->image_height * 3 * sizeof(double);
+    double* d_fb = nullptr;
+    HIP_TRY(hipMalloc(&d_fb, bytes));
+    // unowned pixels keep the caller's values: start from the caller's buffer
+    hipError_t e = hipMemcpy(d_fb, framebuffer, bytes, hipMemcpyHostToDevice);
+    int rc = BDPT_OK;
+    if (e == hipSuccess) {
+        rc = render_impl(ctx, scene, cam, params, d_fb, nullptr);
+        if (rc == BDPT_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(framebuffer, d_fb, bytes, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(d_fb);
+    if (rc != BDPT_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "bdpt_render");
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        if (params->flags & BDPT_RENDER_COUNT_STATS) return bdpt_render_get_stats(ctx, stats);
+    }
+    return BDPT_OK;
+}
+
+int bdpt_colors_to_rgb8(const double* fb, int32_t W, int32_t H, int32_t spp, uint8_t* out) {
+    if (!fb || !out || W <= 0 || H <= 0) return fail(BDPT_ERR_INVALID_ARGUMENT, "bad argument");
+    const double scale = 1.0 / (spp > 1 ? spp : 1);
+    const size_t n = (size_t)W * H * 3;
+    for (size_t i = 0; i < n; i++) {
+        const double c = fb[i] * scale;
+        const double cl = c < 0.0 ? 0.0 : (c > 0.999 ? 0.999 : c);
+        const double v = 256.0 * std::sqrt(cl);
+        out[i] = (v != v) ? 0 : static_cast<uint8_t>(v);
+    }
+    return BDPT_OK;
+}
+
+int bdpt_colors_to_rgb8_device(bdpt_context* ctx, const void* d_fb, int32_t W, int32_t H, int32_t spp, void* d_out,
+                               void* stream) {
+    if (!ctx || !d_fb || !d_out || W <= 0 || H <= 0) return fail(BDPT_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(ctx->device);
+    const double scale = 1.0 / (spp > 1 ? spp : 1);
+    HIP_TRY(launch_rgb8(static_cast<const double*>(d_fb), (uint64_t)W * H * 3, scale, static_cast<uint8_t*>(d_out),
+                        static_cast<hipStream_t>(stream)));
+    return BDPT_OK;
+}
+
+static int run_unary(bdpt_context* ctx, int kind, int op, const double* a, const double* b, uint64_t n, double* o1,
+                     double* o2, uint64_t seed, uint64_t pixel, uint64_t sample) {
+    if (!ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "null context");
+    if (n == 0) return BDPT_OK;
+    DeviceGuard guard(ctx->device);
+    double *d_a = nullptr, *d_b = nullptr, *d_o1 = nullptr, *d_o2 = nullptr;
+    hipError_t e = hipSuccess;
+    const size_t bytes = n * sizeof(double);
+    do {
+        if ((e = hipMalloc(&d_a, bytes)) != hipSuccess) break;
+        if ((e = hipMalloc(&d_b, bytes)) != hipSuccess) break;
+        if ((e = hipMalloc(&d_o1, bytes)) != hipSuccess) break;
+        if ((e = hipMalloc(&d_o2, bytes)) != hipSuccess) break;
+        if (a && (e = hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if (b && (e = hipMemcpy(d_b, b, bytes, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if (kind == 0) e = launch_sincos(d_a, n, d_o1, d_o2, nullptr);
+        else if (kind == 1) e = launch_random(seed, pixel, sample, n, d_o1, nullptr);
+        else e = launch_arith(op, d_a, d_b, n, d_o1, nullptr);
+        if (e != hipSuccess) break;
+        if (o1 && (e = hipMemcpy(o1, d_o1, bytes, hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if (o2 && (e = hipMemcpy(o2, d_o2, bytes, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    } while (0);
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o1); (void)hipFree(d_o2);
+    if (e != hipSuccess) return hip_fail(e, "device test hook");
+    return BDPT_OK;
+}
+
+int bdpt_device_sincos(bdpt_context* ctx, const double* x, uint64_t n, double* sin_out, double* cos_out) {
+    if (n && (!x || !sin_out || !cos_out)) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    return run_unary(ctx, 0, 0, x, nullptr, n, sin_out, cos_out, 0, 0, 0);
+}
+
+int bdpt_device_random_doubles(bdpt_context* ctx, uint64_t seed, uint64_t pixel, uint64_t sample, uint64_t n, double* out) {
+    if (n && !out) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    return run_unary(ctx, 1, 0, nullptr, nullptr, n, out, nullptr, seed, pixel, sample);
+}
+
+int bdpt_device_arith(bdpt_context* ctx, int op, const double* a, const double* b, uint64_t n, double* out) {
+    if (n && (!a || !b || !out)) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    return run_unary(ctx, 2, op, a, b, n, out, nullptr, 0, 0, 0);
+}
+
+}  // extern "C"

@@ -1,0 +1,491 @@
+// Device-side building blocks of the radiance-estimation path: FP64 vector algebra in the
+// reference's evaluation order, the per-sample random stream, the threaded-BVH walk, the
+// materials and the subpath / connection logic.  Citations are to the reference renderer's
+// source tree.  Compile with -ffp-contract=off: every + - * / sqrt below must round exactly
+// once, in the order written.
+#ifndef BDPT_DEVICE_CORE_H
+#define BDPT_DEVICE_CORE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bdpt_types.h"
+#include "det_math.h"
+
+namespace bdpt {
+
+#define BDPT_DEV __device__ __forceinline__
+
+constexpr double kPi = 3.1415926535897932385;                    // src/main.h:20
+constexpr double kInf = __builtin_huge_val();
+
+// ------------------------------------------------------------------ vec3 (src/core/vec3.h)
+struct V3 { double x, y, z; };
+
+BDPT_DEV V3 mk(double a, double b, double c) { V3 v; v.x = a; v.y = b; v.z = c; return v; }
+BDPT_DEV V3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+BDPT_DEV V3 neg(V3 v) { return mk(-v.x, -v.y, -v.z); }
+BDPT_DEV V3 add(V3 u, V3 v) { return mk(u.x + v.x, u.y + v.y, u.z + v.z); }
+BDPT_DEV V3 sub(V3 u, V3 v) { return mk(u.x - v.x, u.y - v.y, u.z - v.z); }
+BDPT_DEV V3 mulv(V3 u, V3 v) { return mk(u.x * v.x, u.y * v.y, u.z * v.z); }
+BDPT_DEV V3 scl(double t, V3 v) { return mk(t * v.x, t * v.y, t * v.z); }
+BDPT_DEV V3 divs(V3 v, double t) { return scl(1 / t, v); }                              // vec3.h:93-95
+BDPT_DEV double dot(V3 u, V3 v) { return u.x * v.x + u.y * v.y + u.z * v.z; }
+BDPT_DEV V3 cross(V3 u, V3 v) {
+    return mk(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+BDPT_DEV double len2(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+BDPT_DEV double len(V3 v) { return __builtin_sqrt(len2(v)); }
+BDPT_DEV V3 unit(V3 v) { return divs(v, len(v)); }                                      // vec3.h:109-111
+BDPT_DEV V3 reflect(V3 v, V3 n) { return sub(v, scl(2 * dot(v, n), n)); }               // vec3.h:138-140
+BDPT_DEV V3 refract(V3 uv, V3 n, double etai_over_etat) {                               // vec3.h:142-147
+    double cos_theta = __builtin_fmin(dot(neg(uv), n), 1.0);
+    V3 r_out_perp = scl(etai_over_etat, add(uv, scl(cos_theta, n)));
+    V3 r_out_parallel = scl(-__builtin_sqrt(__builtin_fabs(1.0 - len2(r_out_perp))), n);
+    return add(r_out_perp, r_out_parallel);
+}
+
+// ------------------------------------------------------------------ random stream (src/main.h:28-37)
+// Each (pixel, sample) owns a counter-based stream; a draw turns one 64-bit word into a double
+// with libstdc++'s generate_canonical formula (g1 + g2*2^32) / 2^64, >= 1 -> nextafter(1, 0).
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ULL;
+
+BDPT_DEV uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+BDPT_DEV uint64_t stream_key(uint64_t seed, uint64_t pixel, uint64_t sample) {
+    uint64_t k = mix64(seed + kGolden * (pixel + 1));
+    return mix64(k ^ (0xD1B54A32D192ED03ULL * (sample + 1)));
+}
+struct Rng {
+    uint64_t key;
+    uint32_t counter;
+    BDPT_DEV double next() {
+        counter++;
+        uint64_t x = mix64(key + (uint64_t)counter * kGolden);
+        double sum = (double)(uint32_t)(x & 0xFFFFFFFFu) + (double)(uint32_t)(x >> 32) * 4294967296.0;
+        double r = sum / 18446744073709551616.0;
+        if (r >= 1.0) r = 0x1.fffffffffffffp-1;
+        return r;
+    }
+    BDPT_DEV double next(double mn, double mx) { return mn + (mx - mn) * next(); }          // main.h:34-37
+};
+
+// vec3.h:121-128; vec3::random(-1,1) fills z first, then y, then x (argument evaluation order of
+// the compiler that built the pinned reference).
+BDPT_DEV V3 random_unit_vector(Rng& rng) {
+    for (;;) {
+        double pz = rng.next(-1, 1);
+        double py = rng.next(-1, 1);
+        double px = rng.next(-1, 1);
+        V3 p = mk(px, py, pz);
+        double lensq = len2(p);
+        if (1e-160 < lensq && lensq <= 1) return divs(p, __builtin_sqrt(lensq));
+    }
+}
+
+BDPT_DEV V3 random_cosine_direction(Rng& rng) {                                           // vec3.h:149-159
+    double r1 = rng.next();
+    double r2 = rng.next();
+    double phi = 2 * kPi * r1;
+    double s, c;
+    det_sincos(phi, s, c);
+    double x = c * __builtin_sqrt(r2);
+    double y = s * __builtin_sqrt(r2);
+    double z = __builtin_sqrt(1 - r2);
+    return mk(x, y, z);
+}
+
+// src/acceleration/onb.h:6-20: returns transform(v) for the basis built around n; w receives axis[2]
+BDPT_DEV V3 onb_transform(V3 n, V3 v, V3& w) {
+    V3 a2 = unit(n);
+    V3 a = (__builtin_fabs(a2.x) > 0.9) ? mk(0, 1, 0) : mk(1, 0, 0);
+    V3 a1 = unit(cross(a2, a));
+    V3 a0 = cross(a2, a1);
+    w = a2;
+    return add(add(scl(v.x, a0), scl(v.y, a1)), scl(v.z, a2));
+}
+
+// ------------------------------------------------------------------ counters
+struct Counters {
+    uint32_t rays_traced, aabb_tests, aabb_hits, node_visits, tri_tests, tri_hits, shadow_rays, pairs;
+};
+
+// ------------------------------------------------------------------ scene access
+// Global-memory view of the scene tables.
+struct GlobalScene {
+    const GpuNode* nodes;
+    const GpuTri* tris;
+    BDPT_DEV GpuNode node(uint32_t i) const { return nodes[i]; }
+    BDPT_DEV GpuTri tri(int32_t i) const { return tris[i]; }
+};
+
+// LDS-resident copy of the node and triangle tables (small scenes): every box / triangle fetch
+// of the walk is a ds_read_b128 burst instead of a trip to L2.
+struct LdsScene {
+    const GpuNode* nodes;     // points into __shared__ memory
+    const GpuTri* tris;
+    BDPT_DEV GpuNode node(uint32_t i) const { return nodes[i]; }
+    BDPT_DEV GpuTri tri(int32_t i) const { return tris[i]; }
+};
+
+struct HitLite {
+    double t, u, v;
+    int32_t tri;
+};
+
+// triangle::hit, src/objects/primatives/triangle.h:41-74 (interval test inclusive, interval.h:22-24)
+BDPT_DEV bool tri_test(const GpuTri& tr, V3 o, V3 d, double tmin, double tmax, double& t_out, double& u_out,
+                       double& v_out) {
+    V3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+    V3 pvec = cross(d, e2);
+    double det = dot(e1, pvec);
+    if (__builtin_fabs(det) < 1e-8) return false;
+    double inv_det = 1.0 / det;
+    V3 tvec = sub(o, ld3(tr.v0));
+    double u = dot(tvec, pvec) * inv_det;
+    if (u < 0.0 || u > 1.0) return false;
+    V3 qvec = cross(tvec, e1);
+    double v = dot(d, qvec) * inv_det;
+    if (v < 0.0 || u + v > 1.0) return false;
+    double t = dot(e2, qvec) * inv_det;
+    if (!(tmin <= t && t <= tmax)) return false;
+    t_out = t; u_out = u; v_out = v;
+    return true;
+}
+
+// bvh_node::hit (src/acceleration/bvh.h:50-59) + aabb::hit (src/acceleration/aabb.h:41-66) as a walk
+// over the threaded tree.  The reference hands every later sibling the closest t found so far
+// (bvh.h:56), so one running `closest` reproduces its intervals; visiting order is the
+// reference's (left subtree, then right), hence equal-t ties resolve identically.
+// ANYHIT returns at the first accepted triangle: the boolean the reference derives from its full
+// closest-hit query (camera.h:437) is the same.
+template <bool STATS, bool ANYHIT, class Mem>
+BDPT_DEV bool walk(const Mem& mem, V3 o, V3 d, double tmin, double tmax, HitLite& hit, Counters& c) {
+    // aabb.h:48 computes 1.0 / dir[axis] inside every box test; the value is the same each time
+    const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;
+    double closest = tmax;
+    bool any = false;
+    uint32_t i = 0;
+    while (i != kEndOfTree) {
+        const GpuNode nd = mem.node(i);
+        if (STATS) { c.node_visits++; c.aabb_tests++; }
+        double lo = tmin, hi = closest;
+        {
+            double t0 = (nd.lo[0] - o.x) * ix, t1 = (nd.hi[0] - o.x) * ix;
+            double nr = (t0 < t1) ? t0 : t1, fr = (t0 < t1) ? t1 : t0;
+            lo = (nr > lo) ? nr : lo; hi = (fr < hi) ? fr : hi;
+        }
+        {
+            double t0 = (nd.lo[1] - o.y) * iy, t1 = (nd.hi[1] - o.y) * iy;
+            double nr = (t0 < t1) ? t0 : t1, fr = (t0 < t1) ? t1 : t0;
+            lo = (nr > lo) ? nr : lo; hi = (fr < hi) ? fr : hi;
+        }
+        {
+            double t0 = (nd.lo[2] - o.z) * iz, t1 = (nd.hi[2] - o.z) * iz;
+            double nr = (t0 < t1) ? t0 : t1, fr = (t0 < t1) ? t1 : t0;
+            lo = (nr > lo) ? nr : lo; hi = (fr < hi) ? fr : hi;
+        }
+        // lo only grows and hi only shrinks, so the reference's per-axis exits (aabb.h:61-62)
+        // fire exactly when this final comparison does
+        if (hi <= lo) { i = nd.skip; continue; }
+        if (STATS) c.aabb_hits++;
+        if (nd.tri0 >= 0) {
+            double t, u, v;
+            {
+                const GpuTri tr = mem.tri(nd.tri0);
+                bool h = tri_test(tr, o, d, tmin, closest, t, u, v);
+                const bool twice = (nd.tri1 == nd.tri0);     // one-triangle node: the reference tests it twice
+                if (STATS) { c.tri_tests += twice ? 2 : 1; if (h) c.tri_hits += twice ? 2 : 1; }
+                if (h) {
+                    if (ANYHIT) return true;
+                    closest = t; hit.t = t; hit.u = u; hit.v = v; hit.tri = nd.tri0; any = true;
+                }
+            }
+            if (nd.tri1 != nd.tri0) {
+                const GpuTri tr = mem.tri(nd.tri1);
+                bool h = tri_test(tr, o, d, tmin, closest, t, u, v);
+                if (STATS) { c.tri_tests++; if (h) c.tri_hits++; }
+                if (h) {
+                    if (ANYHIT) return true;
+                    closest = t; hit.t = t; hit.u = u; hit.v = v; hit.tri = nd.tri1; any = true;
+                }
+            }
+        }
+        i = nd.next;
+    }
+    return any;
+}
+
+// camera::visible, src/camera.h:425-438
+template <bool STATS, class Mem>
+BDPT_DEV bool visible(const Mem& mem, V3 a, V3 b, Counters& c) {
+    V3 dir = sub(b, a);
+    double dist = len(dir);
+    if (dist <= 0) return false;
+    V3 dir_unit = divs(dir, dist);
+    V3 origin = add(a, scl(0.001, dir_unit));
+    double max_t = dist - 0.001;
+    if (max_t <= 0) return false;
+    if (STATS) c.shadow_rays++;
+    HitLite tmp;
+    return !walk<STATS, !STATS>(mem, origin, dir_unit, 0.001, max_t, tmp, c);
+}
+
+// ------------------------------------------------------------------ path vertices
+// What the connection step needs from a path_vertex (src/camera.h:236-243): position, shading
+// normal, throughput, material and three flags.  Delta vertices are never stored: connect_vertices
+// returns zero for them before looking at anything else (camera.h:441).
+constexpr int kVtxDoubles = 10;   // p[3] n[3] T[3] + one slot holding (material | flags)
+constexpr uint32_t kVtxIsLight = 1u << 30;
+constexpr uint32_t kVtxFrontFace = 1u << 29;
+constexpr uint32_t kVtxMatMask = (1u << 29) - 1;
+
+struct Vertex {
+    V3 p, n, T;
+    uint32_t info;
+};
+
+// SoA in global memory: element (slot, field) of thread g lives at ws[(slot*10 + field)*stride + g],
+// so a wave's accesses to one field of one slot are contiguous.
+struct VertexStore {
+    double* ws;
+    uint64_t stride;
+    uint64_t g;
+    BDPT_DEV void put(int slot, const Vertex& v) const {
+        double* b = ws + (uint64_t)slot * kVtxDoubles * stride + g;
+        b[0] = v.p.x; b[stride] = v.p.y; b[2 * stride] = v.p.z;
+        b[3 * stride] = v.n.x; b[4 * stride] = v.n.y; b[5 * stride] = v.n.z;
+        b[6 * stride] = v.T.x; b[7 * stride] = v.T.y; b[8 * stride] = v.T.z;
+        b[9 * stride] = __longlong_as_double((long long)v.info);
+    }
+    BDPT_DEV Vertex get(int slot) const {
+        const double* b = ws + (uint64_t)slot * kVtxDoubles * stride + g;
+        Vertex v;
+        v.p = mk(b[0], b[stride], b[2 * stride]);
+        v.n = mk(b[3 * stride], b[4 * stride], b[5 * stride]);
+        v.T = mk(b[6 * stride], b[7 * stride], b[8 * stride]);
+        v.info = (uint32_t)__double_as_longlong(b[9 * stride]);
+        return v;
+    }
+};
+
+// ------------------------------------------------------------------ materials (src/materials/material.h)
+BDPT_DEV double reflectance(double cosine, double refraction_index) {                      // material.h:125-130
+    double r0 = (1 - refraction_index) / (1 + refraction_index);
+    r0 = r0 * r0;
+    return r0 + (1 - r0) * det_pow5(1 - cosine);
+}
+
+// BSDF value used by connect_vertices: albedo/pi for lambertian (material.h:60-63), zero otherwise (:35-37)
+BDPT_DEV V3 evaluate_bsdf(const GpuMaterial& m) {
+    if (m.type == 0) return divs(ld3(m.rgb), kPi);
+    return mk(0, 0, 0);
+}
+
+// camera::trace_path, src/camera.h:325-370.  Stores the non-delta vertices into `store` starting
+// at slot `slot0`; returns how many were stored.  `n_hits` counts ALL vertices (delta ones too).
+// Eye subpaths (EYE) also return the background term (camera.h:337-338) and the emission term of
+// camera.h:306-309; a path ends at the first emissive surface (material.h:26-28), so there is at
+// most one such term.
+template <bool STATS, bool EYE, class Mem>
+BDPT_DEV int trace_path(const Mem& mem, const SceneDev& sc, const GpuCamera& cam, V3 o, V3 d, int depth, V3 throughput,
+                        Rng& rng, const VertexStore& store, int slot0, Counters& c, int& n_hits, V3& background_contrib,
+                        V3& emitted_term, bool& has_emitted) {
+    int stored = 0;
+    n_hits = 0;
+    for (int bounce = 0; bounce < depth; ++bounce) {
+        if (STATS) c.rays_traced++;
+        HitLite h;
+        if (!walk<STATS, false>(mem, o, d, 0.001, kInf, h, c)) {
+            if (EYE) background_contrib = add(background_contrib, mulv(throughput, ld3(cam.background)));
+            break;
+        }
+        n_hits++;
+        const GpuTriAux ax = sc.aux[h.tri];
+        const int32_t mat_id = mem.tri(h.tri).material;
+        const GpuMaterial m = sc.mats[mat_id];
+        V3 p = add(o, scl(h.t, d));                                           // ray.h:21-23
+        V3 outward = ld3(ax.normal);
+        bool front_face = dot(d, outward) < 0;                                // hittable.h:20-26
+        V3 normal = front_face ? outward : neg(outward);
+
+        if (m.type == 0 || m.type == 3) {                                     // non-delta: keep for the connections
+            Vertex vx;
+            vx.p = p; vx.n = normal; vx.T = throughput;
+            vx.info = (uint32_t)mat_id | (m.type == 3 ? kVtxIsLight : 0u) | (front_face ? kVtxFrontFace : 0u);
+            store.put(slot0 + stored, vx);
+            stored++;
+        }
+        if (m.type == 3) {                                                    // diffuse_light: emits, never scatters
+            if (EYE && front_face) {
+                V3 e = ld3(m.rgb);
+                if (len2(e) > 0) { emitted_term = mulv(throughput, e); has_emitted = true; }
+            }
+            break;
+        }
+        if (m.type == 1) {                                                    // metal, material.h:73-83
+            V3 reflected = reflect(d, normal);
+            reflected = add(unit(reflected), scl(m.fuzz, random_unit_vector(rng)));
+            throughput = mulv(throughput, ld3(m.rgb));
+            o = p; d = reflected;
+            continue;
+        }
+        if (m.type == 2) {                                                    // dielectric, material.h:96-116
+            double ri = front_face ? (1.0 / m.ior) : m.ior;
+            V3 unit_direction = unit(d);
+            double cos_theta = __builtin_fmin(dot(neg(unit_direction), normal), 1.0);
+            double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+            bool cannot_refract = ri * sin_theta > 1.0;
+            V3 direction;
+            if (cannot_refract || reflectance(cos_theta, ri) > rng.next())
+                direction = reflect(unit_direction, normal);
+            else
+                direction = refract(unit_direction, normal, ri);
+            throughput = mulv(throughput, mk(1.0, 1.0, 1.0));
+            o = p; d = direction;
+            continue;
+        }
+        // lambertian, material.h:47-58 + pdf.h:32-47 + camera.h:361-368
+        V3 w;
+        V3 scattered = onb_transform(normal, random_cosine_direction(rng), w);
+        V3 su = unit(scattered);
+        double pdf_value = __builtin_fmax(0.0, dot(su, w) / kPi);
+        if (pdf_value <= 0) break;
+        double cos_theta = dot(normal, su);
+        double scattering_pdf = cos_theta < 0 ? 0 : cos_theta / kPi;
+        throughput = divs(scl(scattering_pdf, mulv(throughput, ld3(m.rgb))), pdf_value);
+        o = p; d = scattered;
+    }
+    return stored;
+}
+
+// triangle_collection::sample_surface + triangle::sample, triangle.h:199-224,107-119.
+// light_accum[i] holds the running area sum exactly as the reference's loop accumulates it, so
+// "first i with pick <= accum[i], else the last triangle" is found by bisection.
+BDPT_DEV int pick_light(const SceneDev& sc, double pick) {
+    int lo = 0, hi = (int)sc.n_lights - 1;       // answer in [lo, hi]; hi is also the fallback
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (pick <= sc.light_accum[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// camera::connect_vertices, src/camera.h:440-475 (both vertices non-delta)
+template <bool STATS, class Mem>
+BDPT_DEV V3 connect(const Mem& mem, const SceneDev& sc, const Vertex& cv, const Vertex& lv, Counters& c) {
+    if (STATS) c.pairs++;
+    V3 dir = sub(lv.p, cv.p);
+    double dist2 = len2(dir);
+    if (dist2 <= 0) return mk(0, 0, 0);
+    V3 dir_unit = unit(dir);
+    double cos_cam = __builtin_fabs(dot(cv.n, dir_unit));
+    double cos_light = __builtin_fabs(dot(lv.n, neg(dir_unit)));
+    if (cos_cam <= 0 || cos_light <= 0) return mk(0, 0, 0);
+    if (!visible<STATS>(mem, cv.p, lv.p, c)) return mk(0, 0, 0);
+    V3 f_cam = evaluate_bsdf(sc.mats[cv.info & kVtxMatMask]);
+    if (len2(f_cam) <= 0) return mk(0, 0, 0);
+    V3 f_light;
+    const GpuMaterial lm = sc.mats[lv.info & kVtxMatMask];
+    if (lv.info & kVtxIsLight) f_light = (lv.info & kVtxFrontFace) ? ld3(lm.rgb) : mk(0, 0, 0);
+    else f_light = evaluate_bsdf(lm);
+    if (len2(f_light) <= 0) return mk(0, 0, 0);
+    V3 contrib = mulv(cv.T, f_cam);
+    contrib = mulv(mulv(contrib, lv.T), f_light);
+    contrib = divs(scl(cos_cam * cos_light, contrib), dist2);
+    return contrib;
+}
+
+// camera::get_ray + ray_color -> bidirectional_color for one sample: src/camera.h:199-223,294-323,372-418
+template <bool STATS, class Mem>
+BDPT_DEV V3 sample_radiance(const Mem& mem, const SceneDev& sc, const GpuCamera& cam, int i, int j, int s_i, int s_j,
+                            uint64_t seed, const VertexStore& store, Counters& c, uint32_t& draws) {
+    Rng rng;
+    rng.key = stream_key(seed, (uint64_t)j * (uint64_t)cam.width + (uint64_t)i, (uint64_t)s_j * cam.sqrt_spp + s_i);
+    rng.counter = 0;
+    const int depth = cam.max_depth;
+
+    // get_ray, camera.h:199-223
+    double px = ((s_i + rng.next()) * cam.recip_sqrt_spp) - 0.5;
+    double py = ((s_j + rng.next()) * cam.recip_sqrt_spp) - 0.5;
+    V3 center = ld3(cam.center);
+    V3 pixel_sample = add(add(ld3(cam.pixel00), scl(i + px, ld3(cam.du))), scl(j + py, ld3(cam.dv)));
+    V3 dir = sub(pixel_sample, center);
+    (void)rng.next();                                                          // ray_time, camera.h:210
+
+    // eye subpath, camera.h:300-309
+    V3 background_contrib = mk(0, 0, 0), emitted_term = mk(0, 0, 0);
+    bool has_emitted = false;
+    int eye_hits = 0, light_hits = 0;
+    int n_eye = trace_path<STATS, true>(mem, sc, cam, center, dir, depth, mk(1, 1, 1), rng, store, 0, c, eye_hits,
+                                        background_contrib, emitted_term, has_emitted);
+    V3 result = background_contrib;
+    if (has_emitted) result = add(result, emitted_term);
+
+    // light subpath, camera.h:372-418
+    int n_light = 0;
+    bool have_light_path = false;
+    if (depth > 0 && sc.n_lights > 0 && sc.light_total_area > 0.0) {
+        double pick = rng.next(0.0, sc.light_total_area);
+        const int li = pick_light(sc, pick);
+        const int32_t tri_id = (int32_t)sc.light_tris[li];
+        double u = rng.next();
+        double v = rng.next();
+        if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
+        const GpuTri tr = mem.tri(tri_id);
+        const GpuTriAux ax = sc.aux[tri_id];
+        V3 position = add(add(ld3(tr.v0), scl(u, ld3(tr.e1))), scl(v, ld3(tr.e2)));
+        V3 normal = ld3(ax.normal);
+        const GpuMaterial m = sc.mats[tr.material];
+        V3 emission = (m.type == 3) ? ld3(m.rgb) : mk(0, 0, 0);                // front_face = true (camera.h:389)
+        if (len2(emission) > 0) {
+            have_light_path = true;
+            double pdf = 1.0 / sc.light_total_area;
+            double pm = (pdf < 1e-8) ? 1e-8 : pdf;                             // std::max(sample.pdf, 1e-8)
+            Vertex ev;
+            ev.p = position; ev.n = normal;
+            ev.T = divs(mk(1.0, 1.0, 1.0), pm);
+            ev.info = (uint32_t)tr.material | kVtxIsLight | kVtxFrontFace;
+            store.put(depth, ev);
+            n_light = 1;
+            light_hits = 1;
+            V3 w;
+            V3 ldir = onb_transform(normal, random_cosine_direction(rng), w);  // camera.h:420-423
+            V3 dir_unit = unit(ldir);
+            double dt = dot(normal, dir_unit);
+            double cos_theta = (0.0 < dt) ? dt : 0.0;                          // std::max(0.0, dot)
+            if (cos_theta > 0) {
+                double q = cos_theta / kPi;
+                double pdf_dir = (q < 1e-8) ? 1e-8 : q;                        // std::max(cos/pi, 1e-8)
+                V3 throughput = scl(cos_theta / pdf_dir, mulv(ev.T, emission));
+                V3 lo = add(position, scl(0.001, normal));
+                V3 dummy_bg = mk(0, 0, 0), dummy_e = mk(0, 0, 0);
+                bool dummy_flag = false;
+                int lh = 0;
+                n_light += trace_path<STATS, false>(mem, sc, cam, lo, dir_unit, depth - 1, throughput, rng, store,
+                                                    depth + 1, c, lh, dummy_bg, dummy_e, dummy_flag);
+                light_hits += lh;
+            }
+        }
+    }
+    draws = rng.counter;
+    if (!have_light_path) return result;
+
+    // connections, camera.h:316-320.  The reference adds a (possibly zero) colour for every pair;
+    // adding +0 only matters for a -0 accumulator, which the first add below normalises.
+    if (eye_hits > 0 && light_hits > 0) result = add(result, mk(0, 0, 0));
+    for (int a = 0; a < n_eye; a++) {
+        const Vertex cv = store.get(a);
+        for (int b = 0; b < n_light; b++) {
+            const Vertex lv = store.get(depth + b);
+            result = add(result, connect<STATS>(mem, sc, cv, lv, c));
+        }
+    }
+    return result;
+}
+
+}  // namespace bdpt
+#endif

@@ -1,0 +1,36 @@
+// Host-side scene preparation: per-triangle precompute, the reference-equivalent BVH build and
+// the flattening into the device tables of bdpt_types.h.
+#ifndef BDPT_SCENE_BUILD_H
+#define BDPT_SCENE_BUILD_H
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/bdpt_amd.h"
+#include "bdpt_types.h"
+
+namespace bdpt {
+
+struct HostScene {
+    std::vector<GpuNode> nodes;          // pre-order (root first); links already threaded
+    std::vector<GpuTri> tris;
+    std::vector<GpuTriAux> aux;
+    std::vector<GpuMaterial> mats;
+    std::vector<uint32_t> light_tris;
+    std::vector<double> light_accum;
+    double light_total_area = 0.0;
+    std::vector<uint32_t> dfs_leaves;    // triangle ids in the reference's leaf visiting order
+    uint32_t tree_depth = 0;
+};
+
+// Returns an empty string on success, an error message otherwise.
+std::string build_host_scene(const double* tri_vertices, const int32_t* tri_material, uint32_t n_triangles,
+                             const bdpt_material* materials, uint32_t n_materials, const uint32_t* light_triangles,
+                             uint32_t n_lights, HostScene& out);
+
+// camera::initialize, src/camera.h:160-197
+std::string camera_initialize(const bdpt_camera_public& cam, bdpt_camera_state& out);
+
+}  // namespace bdpt
+#endif

@@ -1,0 +1,203 @@
+/* bdpt_amd.h - C ABI of the MI355X (gfx950) radiance-estimation library.
+ *
+ * Drop-in boundary for the per-pixel hot path of teehee567/Bidirectional-Path-Tracer:
+ * everything between "the scene is a triangle soup + material table + camera"
+ * (what load_scene_from_yaml returns, src/scene/scene_loader.h:22-28,480-523) and
+ * "a framebuffer of per-pixel radiance SUMS" (src/camera.h:55,124).  The reference has
+ * no FFI of its own; each entry point names the C++ call of the reference it replaces.
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every function returns
+ * BDPT_OK (0) or a negative error code; bdpt_last_error() returns the message of the
+ * calling thread's last failure.  Handles are opaque.  The caller owns every host
+ * buffer it passes; the library owns all device memory except buffers the caller
+ * passes to the *_device entry points.  A context belongs to one GPU and is not
+ * thread-safe; different contexts may be used from different threads.  All
+ * floating-point data is IEEE binary64, as in the reference (src/core/vec3.h:9).
+ */
+#ifndef BDPT_AMD_H
+#define BDPT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDPT_OK 0
+#define BDPT_ERR_INVALID_ARGUMENT (-1)
+#define BDPT_ERR_DEVICE (-2)          /* a HIP call failed / no usable GPU */
+#define BDPT_ERR_OUT_OF_MEMORY (-3)
+#define BDPT_ERR_UNSUPPORTED (-4)
+
+typedef struct bdpt_context bdpt_context;
+typedef struct bdpt_scene bdpt_scene;
+
+/* Material kinds (src/materials/material.h:42-147). */
+enum {
+    BDPT_LAMBERTIAN = 0,     /* rgb = albedo                      material.h:42-67   */
+    BDPT_METAL = 1,          /* rgb = albedo, fuzz (clamped to 1) material.h:69-90   */
+    BDPT_DIELECTRIC = 2,     /* ior                               material.h:92-131  */
+    BDPT_DIFFUSE_LIGHT = 3   /* rgb = emitted radiance            material.h:133-147 */
+};
+
+typedef struct bdpt_material {
+    int32_t type;
+    int32_t reserved;
+    double rgb[3];
+    double fuzz;
+    double ior;
+} bdpt_material;
+
+/* Public camera fields, src/camera.h:26-38 (defocus blur is disabled by the reference's
+ * loader, src/scene/scene_loader.h:463, and is not supported: defocus_angle must be <= 0). */
+typedef struct bdpt_camera_public {
+    double lookfrom[3];
+    double lookat[3];
+    double vup[3];
+    double vfov;
+    double aspect_ratio;
+    double focus_dist;
+    double defocus_angle;
+    double background[3];
+    int32_t image_width;
+    int32_t samples_per_pixel;
+    int32_t max_depth;
+    int32_t reserved;
+} bdpt_camera_public;
+
+/* What camera::initialize derives (src/camera.h:148-155,160-197). */
+typedef struct bdpt_camera_state {
+    double center[3];
+    double pixel00_loc[3];
+    double pixel_delta_u[3];
+    double pixel_delta_v[3];
+    double background[3];
+    int32_t image_width;
+    int32_t image_height;
+    int32_t sqrt_spp;        /* int(sqrt(samples_per_pixel)); sqrt_spp^2 samples are taken (camera.h:164) */
+    int32_t max_depth;
+} bdpt_camera_state;
+
+/* One render call = the worker loop of camera::render (src/camera.h:111-129) over the
+ * pixels this call owns.  Pixels are owned when they lie in the rectangle [x0,x1) x [y0,y1)
+ * AND their row j satisfies (j / shard_rows) % shard_count == shard_index (row bands dealt
+ * round-robin to the GPUs of a node; shard_count = 1 owns everything).  Pixels not owned
+ * are left untouched, so summing the framebuffers of all shards of a zero-initialised
+ * image gives the unsharded image exactly.  Random numbers: sample s of pixel p always
+ * uses stream (seed, p = j*image_width + i, s = s_j*sqrt_spp + s_i), whatever the sharding. */
+typedef struct bdpt_render_params {
+    uint64_t seed;
+    int32_t x0, y0, x1, y1;     /* x1 <= 0 or y1 <= 0 means "up to the image edge" */
+    int32_t shard_index;
+    int32_t shard_count;        /* 0 is treated as 1 */
+    int32_t shard_rows;         /* 0 is treated as 1 */
+    int32_t flags;              /* BDPT_RENDER_* */
+} bdpt_render_params;
+
+#define BDPT_RENDER_COUNT_STATS 1   /* also accumulate bdpt_stats (slower) */
+
+/* Work counters.  The first six have the meaning of the reference's BvhStats
+ * (src/core/stats.h:8-16); a triangle referenced twice by a one-triangle BVH node is
+ * tested once here and counted twice, as the reference does. */
+typedef struct bdpt_stats {
+    uint64_t rays_traced;       /* closest-hit queries of trace_path (camera.h:334) */
+    uint64_t aabb_tests;
+    uint64_t aabb_hits;
+    uint64_t bvh_node_visits;
+    uint64_t triangle_tests;
+    uint64_t triangle_hits;
+    uint64_t shadow_rays;       /* visibility queries that reached the BVH (camera.h:437) */
+    uint64_t connection_pairs;  /* non-delta (eye, light) vertex pairs (camera.h:441) */
+    uint64_t rng_draws;
+    uint64_t samples;           /* (pixel, sample) pairs rendered */
+} bdpt_stats;
+
+typedef struct bdpt_scene_info {
+    uint32_t n_triangles;
+    uint32_t n_materials;
+    uint32_t n_lights;          /* size of the light collection actually used (whole world if none emissive) */
+    uint32_t n_nodes;           /* bvh_node objects the reference would build */
+    uint32_t max_depth;         /* depth of the tree */
+    uint32_t reserved;
+    uint64_t device_bytes;
+} bdpt_scene_info;
+
+const char* bdpt_last_error(void);
+
+/* Library / device set-up.  No counterpart in the reference (it is a CPU program). */
+int bdpt_context_create(int device_index, bdpt_context** out);
+int bdpt_context_destroy(bdpt_context* ctx);
+
+/* camera::initialize(), src/camera.h:160-197 (host arithmetic, glibc tan). */
+int bdpt_camera_initialize(const bdpt_camera_public* cam, bdpt_camera_state* out);
+
+/* Replaces `make_shared<bvh_node>(scene.world.to_hittable_list())` and the choice of the light
+ * collection in main (src/main.cpp:66-67, src/acceleration/bvh.h:13-48,
+ * src/objects/primatives/triangle.h:21-39,191-197): precomputes the triangles, builds the
+ * reference-equivalent BVH on the host (same comparator, same std::sort, same box padding ->
+ * same topology and left-to-right order) and uploads the flattened tables.
+ *   tri_vertices : n_triangles * 9 doubles (v0 v1 v2), world order of triangle_collection::add
+ *   tri_material : n_triangles indices into materials
+ *   light_triangles : ids of the triangles of the `lights` collection in insertion order
+ *                     (scene_loader.h:190-202); n_lights == 0 selects the whole world (main.cpp:67). */
+int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32_t* tri_material,
+                      uint32_t n_triangles, const bdpt_material* materials, uint32_t n_materials,
+                      const uint32_t* light_triangles, uint32_t n_lights, bdpt_scene** out);
+int bdpt_scene_destroy(bdpt_scene* scene);
+int bdpt_scene_get_info(const bdpt_scene* scene, bdpt_scene_info* out);
+/* Triangle ids in the reference's left-then-right leaf visiting order (a one-triangle node lists
+ * its triangle twice, bvh.h:35-36).  *count receives the number of entries (<= 2*n_triangles). */
+int bdpt_scene_dfs_leaves(const bdpt_scene* scene, uint32_t* out, uint32_t capacity, uint32_t* count);
+/* Boxes of the bvh_node objects in pre-order: xmin xmax ymin ymax zmin zmax (6 doubles per node). */
+int bdpt_scene_node_boxes(const bdpt_scene* scene, double* out, uint32_t capacity_nodes);
+
+/* bvh_node::hit(r, interval(tmin, tmax), rec), src/acceleration/bvh.h:50-59, for n rays.
+ *   rays : n * 8 doubles (origin[3] direction[3] tmin tmax)
+ *   hits : n * 11 doubles (triangle id or -1, t, u, v, front_face, p[3], normal[3]) = hit_record
+ *          (src/objects/hittable.h:10-27) plus the id of the triangle
+ *   stats: optional. */
+int bdpt_trace_closest(bdpt_context* ctx, const bdpt_scene* scene, const double* rays, uint64_t n,
+                       double* hits, bdpt_stats* stats);
+/* Same with rays / hits already in device memory (HBM-resident, asynchronous on `stream`,
+ * a hipStream_t or NULL). */
+int bdpt_trace_closest_device(bdpt_context* ctx, const bdpt_scene* scene, const void* d_rays, uint64_t n,
+                              void* d_hits, void* stream);
+
+/* camera::visible(a, b, world), src/camera.h:425-438, for n point pairs (a[3] b[3]); out: n bytes (0/1). */
+int bdpt_visible(bdpt_context* ctx, const bdpt_scene* scene, const double* pairs, uint64_t n, uint8_t* out);
+
+/* The worker loop of camera::render, src/camera.h:111-129 (-> get_ray :199-223, ray_color :245-253,
+ * bidirectional_color :294-323 and everything below it).  framebuffer: image_width*image_height*3
+ * doubles, row-major, the per-pixel SUM over the sqrt_spp^2 samples (camera.h:124); only owned
+ * pixels are written.  stats: optional, filled when BDPT_RENDER_COUNT_STATS is set. */
+int bdpt_render(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam,
+                const bdpt_render_params* params, double* framebuffer, bdpt_stats* stats);
+/* Same, framebuffer in device memory; returns after enqueueing on `stream` (hipStream_t or NULL). */
+int bdpt_render_device(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam,
+                       const bdpt_render_params* params, void* d_framebuffer, void* stream);
+/* Counters of the last bdpt_render_device call that had BDPT_RENDER_COUNT_STATS set (synchronises). */
+int bdpt_render_get_stats(bdpt_context* ctx, bdpt_stats* out);
+
+/* colors_to_rgb8(), src/image/wpng.h:14-35: sum/spp -> clamp [0,0.999] -> sqrt -> *256 -> u8.
+ * NaN (undefined behaviour in the reference) maps to 0. */
+int bdpt_colors_to_rgb8(const double* framebuffer, int32_t width, int32_t height, int32_t samples_per_pixel,
+                        uint8_t* out_rgb);
+int bdpt_colors_to_rgb8_device(bdpt_context* ctx, const void* d_framebuffer, int32_t width, int32_t height,
+                               int32_t samples_per_pixel, void* d_out_rgb, void* stream);
+
+/* Test hooks for the device-side building blocks the path is made of. */
+/* std::cos / std::sin of src/core/vec3.h:154-155 as evaluated on the GPU (0 <= x <= 8). */
+int bdpt_device_sincos(bdpt_context* ctx, const double* x, uint64_t n, double* sin_out, double* cos_out);
+/* first n values random_double() returns inside sample `sample` of pixel `pixel` (src/main.h:28-32). */
+int bdpt_device_random_doubles(bdpt_context* ctx, uint64_t seed, uint64_t pixel, uint64_t sample, uint64_t n,
+                               double* out);
+
+/* element-wise IEEE checks on the GPU: op 0 a/b, 1 sqrt(a), 2 fma(a,b,a), 3 a*b+a (two roundings),
+ * 4 fmin, 5 fmax, 6 a^5 as the device evaluates pow(.,5) of src/materials/material.h:129, 7 1/a */
+int bdpt_device_arith(bdpt_context* ctx, int op, const double* a, const double* b, uint64_t n, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
