@@ -13,7 +13,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbdpt_amd.so")
 
-BDPT_RENDER_COUNT_STATS = 1
+BDPT_RENDER_COUNT_STATS = 1     # counters with the reference's BvhStats semantics
+BDPT_RENDER_COUNT_WORK = 2      # counters of the work the production path does
+BDPT_RENDER_TIME_KERNEL = 4     # HIP events around the render kernel
 
 
 class BdptError(RuntimeError):
@@ -49,7 +51,8 @@ class RenderParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays_traced", "aabb_tests", "aabb_hits", "bvh_node_visits", "triangle_tests",
-                                          "triangle_hits", "shadow_rays", "connection_pairs", "rng_draws", "samples")]
+                                          "triangle_hits", "shadow_rays", "connection_pairs", "rng_draws", "samples",
+                                          "path_vertices")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -66,6 +69,7 @@ EXPORTED_SYMBOLS = [
     "bdpt_last_error", "bdpt_context_create", "bdpt_context_destroy", "bdpt_camera_initialize", "bdpt_scene_create",
     "bdpt_scene_destroy", "bdpt_scene_get_info", "bdpt_scene_dfs_leaves", "bdpt_scene_node_boxes", "bdpt_trace_closest",
     "bdpt_trace_closest_device", "bdpt_visible", "bdpt_render", "bdpt_render_device", "bdpt_render_get_stats",
+    "bdpt_render_get_kernel_ms",
     "bdpt_colors_to_rgb8", "bdpt_colors_to_rgb8_device", "bdpt_device_sincos", "bdpt_device_random_doubles",
     "bdpt_device_arith",
 ]
@@ -77,6 +81,14 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own libamdhip64 (same soname as ROCm's).  Two HIP runtimes in one process
+    # cannot both own the GPU, so when torch is going to be used (device buffers, RCCL) it has to be
+    # loaded first: this library then binds to the runtime that is already there.
+    if os.environ.get("BDPT_NO_TORCH", "") == "":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise BdptError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(there is no CPU fallback)" % LIB_PATH)
@@ -97,6 +109,7 @@ def load_library() -> C.CDLL:
     lib.bdpt_render.argtypes = [vp, vp, C.POINTER(CameraState), C.POINTER(RenderParams), vp, C.POINTER(Stats)]
     lib.bdpt_render_device.argtypes = [vp, vp, C.POINTER(CameraState), C.POINTER(RenderParams), vp, vp]
     lib.bdpt_render_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.bdpt_render_get_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.bdpt_colors_to_rgb8.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.bdpt_colors_to_rgb8_device.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
     lib.bdpt_device_sincos.argtypes = [vp, vp, u64, vp, vp]
@@ -245,6 +258,16 @@ class Scene:
         _check(self.lib.bdpt_visible(self.ctx.h, self.h, _ptr(pairs), len(pairs), _ptr(out)))
         return out
 
+    @staticmethod
+    def _flags(want_stats, time_kernel=False):
+        """want_stats: False / True or "reference" (BvhStats semantics) / "work" (production path's own work)"""
+        f = BDPT_RENDER_TIME_KERNEL if time_kernel else 0
+        if want_stats == "work":
+            f |= BDPT_RENDER_COUNT_WORK
+        elif want_stats:
+            f |= BDPT_RENDER_COUNT_STATS
+        return f
+
     def render(self, cam_state: CameraState, seed=0, rect=None, shard=(0, 1, 1), want_stats=False, framebuffer=None):
         """Host-buffer render; returns the full W x H x 3 framebuffer of sums (unowned pixels keep
         the values of `framebuffer`, zeros by default) and optionally the counters."""
@@ -255,22 +278,27 @@ class Scene:
         if rect is not None:
             p.x0, p.y0, p.x1, p.y1 = [int(v) for v in rect]
         p.shard_index, p.shard_count, p.shard_rows = shard
-        p.flags = BDPT_RENDER_COUNT_STATS if want_stats else 0
+        p.flags = self._flags(want_stats)
         st = Stats()
         _check(self.lib.bdpt_render(self.ctx.h, self.h, C.byref(cam_state), C.byref(p), _ptr(fb), C.byref(st)))
         return (fb, st) if want_stats else fb
 
     def render_device(self, cam_state: CameraState, d_framebuffer: int, seed=0, rect=None, shard=(0, 1, 1),
-                      want_stats=False, stream: int = 0):
+                      want_stats=False, stream: int = 0, time_kernel=False):
         """Framebuffer already in device memory (`d_framebuffer` = device pointer, e.g. tensor.data_ptr())."""
         p = RenderParams()
         p.seed = seed
         if rect is not None:
             p.x0, p.y0, p.x1, p.y1 = [int(v) for v in rect]
         p.shard_index, p.shard_count, p.shard_rows = shard
-        p.flags = BDPT_RENDER_COUNT_STATS if want_stats else 0
+        p.flags = self._flags(want_stats, time_kernel)
         _check(self.lib.bdpt_render_device(self.ctx.h, self.h, C.byref(cam_state), C.byref(p), C.c_void_p(d_framebuffer),
                                            C.c_void_p(stream)))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _check(self.lib.bdpt_render_get_kernel_ms(self.ctx.h, C.byref(ms)))
+        return float(ms.value)
 
     def last_stats(self) -> Stats:
         st = Stats()

@@ -36,7 +36,7 @@ int hip_fail(hipError_t e, const char* what) {
     } while (0)
 
 constexpr int kBlock = 256;
-constexpr int kStatWords = 10;
+constexpr int kStatWords = 11;
 
 }  // namespace
 
@@ -51,6 +51,8 @@ struct bdpt_context {
     uint32_t* unit_counter = nullptr;
     unsigned long long* stats = nullptr;
     bool stats_valid = false;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // bracket the render kernel on its own stream
+    bool timing_valid = false;
 };
 
 struct bdpt_scene {
@@ -99,7 +101,7 @@ int ensure_vertex_ws(bdpt_context* ctx, size_t bytes) {
 void read_stats(const unsigned long long* h, bdpt_stats* out) {
     out->rays_traced = h[0]; out->aabb_tests = h[1]; out->aabb_hits = h[2]; out->bvh_node_visits = h[3];
     out->triangle_tests = h[4]; out->triangle_hits = h[5]; out->shadow_rays = h[6]; out->connection_pairs = h[7];
-    out->rng_draws = h[8]; out->samples = h[9];
+    out->rng_draws = h[8]; out->samples = h[9]; out->path_vertices = h[10];
 }
 
 GpuCamera to_gpu_camera(const bdpt_camera_state& c) {
@@ -129,7 +131,9 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     const int shard_count = p->shard_count <= 0 ? 1 : p->shard_count;
     const int shard_rows = p->shard_rows <= 0 ? 1 : p->shard_rows;
     if (p->shard_index < 0 || p->shard_index >= shard_count) return fail(BDPT_ERR_INVALID_ARGUMENT, "shard_index out of range");
-    const bool want_stats = (p->flags & BDPT_RENDER_COUNT_STATS) != 0;
+    const int stats_mode = (p->flags & BDPT_RENDER_COUNT_STATS) ? 1 : ((p->flags & BDPT_RENDER_COUNT_WORK) ? 2 : 0);
+    const bool want_stats = stats_mode != 0;
+    const bool want_time = (p->flags & BDPT_RENDER_TIME_KERNEL) != 0;
     ctx->stats_valid = false;
     if (want_stats) HIP_TRY(hipMemsetAsync(ctx->stats, 0, sizeof(unsigned long long) * kStatWords, stream));
     if (x0 >= x1 || y0 >= y1) { ctx->stats_valid = want_stats; return BDPT_OK; }
@@ -153,7 +157,7 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
 
     // persistent grid: enough workgroups to fill the chip, never more than there is work
     int per_cu = 1;
-    HIP_TRY(render_blocks_per_cu(scene->dev, want_stats, &per_cu));
+    HIP_TRY(render_blocks_per_cu(scene->dev, stats_mode, &per_cu));
     int64_t grid = (int64_t)ctx->cu_count * per_cu;
     if (grid > n_units) grid = n_units;
     const size_t ws_stride = (size_t)grid * kBlock;
@@ -173,7 +177,10 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     rl.vertex_ws = ctx->vertex_ws;
     rl.stats = want_stats ? ctx->stats : nullptr;
     rl.ws_stride = ws_stride;
-    HIP_TRY(launch_render(scene->dev, to_gpu_camera(*cam), rl, (int)grid, want_stats, stream));
+    ctx->timing_valid = false;
+    if (want_time) HIP_TRY(hipEventRecord(ctx->ev_start, stream));
+    HIP_TRY(launch_render(scene->dev, to_gpu_camera(*cam), rl, (int)grid, stats_mode, stream));
+    if (want_time) { HIP_TRY(hipEventRecord(ctx->ev_stop, stream)); ctx->timing_valid = true; }
     ctx->stats_valid = want_stats;
     return BDPT_OK;
 }
@@ -200,7 +207,8 @@ int bdpt_context_create(int device_index, bdpt_context** out) {
     if (!ctx) return fail(BDPT_ERR_OUT_OF_MEMORY, "host allocation failed");
     ctx->device = device_index;
     ctx->cu_count = prop.multiProcessorCount;
-    if (hipMalloc(&ctx->unit_counter, 256) != hipSuccess || hipMalloc(&ctx->stats, 256) != hipSuccess) {
+    if (hipMalloc(&ctx->unit_counter, 256) != hipSuccess || hipMalloc(&ctx->stats, 256) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
         bdpt_context_destroy(ctx);
         return fail(BDPT_ERR_OUT_OF_MEMORY, "device allocation failed");
     }
@@ -216,6 +224,8 @@ int bdpt_context_destroy(bdpt_context* ctx) {
     if (ctx->rows) (void)hipFree(ctx->rows);
     if (ctx->unit_counter) (void)hipFree(ctx->unit_counter);
     if (ctx->stats) (void)hipFree(ctx->stats);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;
     return BDPT_OK;
 }
@@ -394,12 +404,21 @@ int bdpt_render_device(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_ca
 
 int bdpt_render_get_stats(bdpt_context* ctx, bdpt_stats* out) {
     if (!ctx || !out) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
-    if (!ctx->stats_valid) return fail(BDPT_ERR_INVALID_ARGUMENT, "the last render did not request BDPT_RENDER_COUNT_STATS");
+    if (!ctx->stats_valid) return fail(BDPT_ERR_INVALID_ARGUMENT, "the last render did not request counters");
     DeviceGuard guard(ctx->device);
     HIP_TRY(hipDeviceSynchronize());
     unsigned long long h[kStatWords];
     HIP_TRY(hipMemcpy(h, ctx->stats, sizeof h, hipMemcpyDeviceToHost));
     read_stats(h, out);
+    return BDPT_OK;
+}
+
+int bdpt_render_get_kernel_ms(bdpt_context* ctx, float* out_ms) {
+    if (!ctx || !out_ms) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->timing_valid) return fail(BDPT_ERR_INVALID_ARGUMENT, "the last render did not request BDPT_RENDER_TIME_KERNEL");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+    HIP_TRY(hipEventElapsedTime(out_ms, ctx->ev_start, ctx->ev_stop));
     return BDPT_OK;
 }
 
@@ -426,7 +445,7 @@ int bdpt_render(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     if (e != hipSuccess) return hip_fail(e, "bdpt_render");
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
-        if (params->flags & BDPT_RENDER_COUNT_STATS) return bdpt_render_get_stats(ctx, stats);
+        if (params->flags & (BDPT_RENDER_COUNT_STATS | BDPT_RENDER_COUNT_WORK)) return bdpt_render_get_stats(ctx, stats);
     }
     return BDPT_OK;
 }

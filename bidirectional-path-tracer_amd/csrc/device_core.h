@@ -109,8 +109,13 @@ BDPT_DEV V3 onb_transform(V3 n, V3 v, V3& w) {
 }
 
 // ------------------------------------------------------------------ counters
+// Counting modes of the kernels: none; the reference's BvhStats semantics (shadow rays run the
+// reference's full closest-hit query so that every counter equals the CPU renderer's); the work
+// the production path really does (shadow rays stop at the first hit).
+constexpr int kStatsOff = 0, kStatsReference = 1, kStatsWork = 2;
+
 struct Counters {
-    uint32_t rays_traced, aabb_tests, aabb_hits, node_visits, tri_tests, tri_hits, shadow_rays, pairs;
+    uint32_t rays_traced, aabb_tests, aabb_hits, node_visits, tri_tests, tri_hits, shadow_rays, pairs, vertices;
 };
 
 // ------------------------------------------------------------------ scene access
@@ -162,7 +167,7 @@ BDPT_DEV bool tri_test(const GpuTri& tr, V3 o, V3 d, double tmin, double tmax, d
 // reference's (left subtree, then right), hence equal-t ties resolve identically.
 // ANYHIT returns at the first accepted triangle: the boolean the reference derives from its full
 // closest-hit query (camera.h:437) is the same.
-template <bool STATS, bool ANYHIT, class Mem>
+template <int STATS, bool ANYHIT, class Mem>
 BDPT_DEV bool walk(const Mem& mem, V3 o, V3 d, double tmin, double tmax, HitLite& hit, Counters& c) {
     // aabb.h:48 computes 1.0 / dir[axis] inside every box test; the value is the same each time
     const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;
@@ -220,7 +225,7 @@ BDPT_DEV bool walk(const Mem& mem, V3 o, V3 d, double tmin, double tmax, HitLite
 }
 
 // camera::visible, src/camera.h:425-438
-template <bool STATS, class Mem>
+template <int STATS, class Mem>
 BDPT_DEV bool visible(const Mem& mem, V3 a, V3 b, Counters& c) {
     V3 dir = sub(b, a);
     double dist = len(dir);
@@ -231,7 +236,7 @@ BDPT_DEV bool visible(const Mem& mem, V3 a, V3 b, Counters& c) {
     if (max_t <= 0) return false;
     if (STATS) c.shadow_rays++;
     HitLite tmp;
-    return !walk<STATS, !STATS>(mem, origin, dir_unit, 0.001, max_t, tmp, c);
+    return !walk<STATS, STATS != kStatsReference>(mem, origin, dir_unit, 0.001, max_t, tmp, c);
 }
 
 // ------------------------------------------------------------------ path vertices
@@ -290,7 +295,7 @@ BDPT_DEV V3 evaluate_bsdf(const GpuMaterial& m) {
 // Eye subpaths (EYE) also return the background term (camera.h:337-338) and the emission term of
 // camera.h:306-309; a path ends at the first emissive surface (material.h:26-28), so there is at
 // most one such term.
-template <bool STATS, bool EYE, class Mem>
+template <int STATS, bool EYE, class Mem>
 BDPT_DEV int trace_path(const Mem& mem, const SceneDev& sc, const GpuCamera& cam, V3 o, V3 d, int depth, V3 throughput,
                         Rng& rng, const VertexStore& store, int slot0, Counters& c, int& n_hits, V3& background_contrib,
                         V3& emitted_term, bool& has_emitted) {
@@ -318,6 +323,7 @@ BDPT_DEV int trace_path(const Mem& mem, const SceneDev& sc, const GpuCamera& cam
             vx.info = (uint32_t)mat_id | (m.type == 3 ? kVtxIsLight : 0u) | (front_face ? kVtxFrontFace : 0u);
             store.put(slot0 + stored, vx);
             stored++;
+            if (STATS) c.vertices++;
         }
         if (m.type == 3) {                                                    // diffuse_light: emits, never scatters
             if (EYE && front_face) {
@@ -375,7 +381,7 @@ BDPT_DEV int pick_light(const SceneDev& sc, double pick) {
 }
 
 // camera::connect_vertices, src/camera.h:440-475 (both vertices non-delta)
-template <bool STATS, class Mem>
+template <int STATS, class Mem>
 BDPT_DEV V3 connect(const Mem& mem, const SceneDev& sc, const Vertex& cv, const Vertex& lv, Counters& c) {
     if (STATS) c.pairs++;
     V3 dir = sub(lv.p, cv.p);
@@ -400,7 +406,7 @@ BDPT_DEV V3 connect(const Mem& mem, const SceneDev& sc, const Vertex& cv, const 
 }
 
 // camera::get_ray + ray_color -> bidirectional_color for one sample: src/camera.h:199-223,294-323,372-418
-template <bool STATS, class Mem>
+template <int STATS, class Mem>
 BDPT_DEV V3 sample_radiance(const Mem& mem, const SceneDev& sc, const GpuCamera& cam, int i, int j, int s_i, int s_j,
                             uint64_t seed, const VertexStore& store, Counters& c, uint32_t& draws) {
     Rng rng;
@@ -450,6 +456,7 @@ BDPT_DEV V3 sample_radiance(const Mem& mem, const SceneDev& sc, const GpuCamera&
             ev.T = divs(mk(1.0, 1.0, 1.0), pm);
             ev.info = (uint32_t)tr.material | kVtxIsLight | kVtxFrontFace;
             store.put(depth, ev);
+            if (STATS) c.vertices++;
             n_light = 1;
             light_hits = 1;
             V3 w;

@@ -24,10 +24,10 @@ __device__ __forceinline__ void stage_scene_to_lds(const SceneDev& sc, GpuNode* 
 __device__ __forceinline__ void flush_counters(const Counters& c, uint32_t draws, uint32_t samples,
                                                unsigned long long* stats) {
     // one atomic per counter per lane would be wasteful: reduce across the wave first
-    unsigned long long v[10] = {c.rays_traced, c.aabb_tests, c.aabb_hits, c.node_visits, c.tri_tests,
-                                c.tri_hits,    c.shadow_rays, c.pairs,    draws,         samples};
+    unsigned long long v[11] = {c.rays_traced, c.aabb_tests, c.aabb_hits, c.node_visits, c.tri_tests,
+                                c.tri_hits,    c.shadow_rays, c.pairs,    draws,         samples,       c.vertices};
 #pragma unroll
-    for (int k = 0; k < 10; k++) {
+    for (int k = 0; k < 11; k++) {
         unsigned long long x = v[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
@@ -39,7 +39,7 @@ __device__ __forceinline__ void flush_counters(const Counters& c, uint32_t draws
 // renders one sample; the per-pixel SUM is formed in the reference's order (s_j outer, s_i inner,
 // camera.h:118-123) by one lane per colour channel reading the samples from LDS, so the FP64 sum
 // is bit-identical to the sequential loop.
-template <bool STATS, bool LDS_SCENE>
+template <int STATS, bool LDS_SCENE>
 __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev sc, GpuCamera cam, RenderLaunch rl) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* l_samples = reinterpret_cast<double*>(smem);                 // kBlock * 3
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev sc, GpuCamera c
     store.stride = rl.ws_stride;
     store.g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 
-    Counters c = {0, 0, 0, 0, 0, 0, 0, 0};
+    Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t total_draws = 0, total_samples = 0;
 
     for (;;) {
@@ -122,14 +122,14 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev sc, GpuCamera c
     if (STATS) flush_counters(c, total_draws, total_samples, rl.stats);
 }
 
-template <bool STATS, bool LDS_SCENE>
+template <int STATS, bool LDS_SCENE>
 __global__ __launch_bounds__(kBlock) void trace_closest_kernel(SceneDev sc, const double* rays, uint64_t n, double* hits,
                                                                 unsigned long long* stats) {
     extern __shared__ __align__(16) unsigned char smem[];
     GpuNode* l_nodes = reinterpret_cast<GpuNode*>(smem);
     GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_nodes);
     if (LDS_SCENE) stage_scene_to_lds(sc, l_nodes, l_tris);
-    Counters c = {0, 0, 0, 0, 0, 0, 0, 0};
+    Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (uint64_t)gridDim.x * kBlock) {
         const double* in = rays + 8 * r;
         V3 o = mk(in[0], in[1], in[2]), d = mk(in[3], in[4], in[5]);
@@ -155,11 +155,11 @@ __global__ __launch_bounds__(kBlock) void trace_closest_kernel(SceneDev sc, cons
 }
 
 __global__ __launch_bounds__(kBlock) void visible_kernel(SceneDev sc, const double* pairs, uint64_t n, uint8_t* out) {
-    Counters c = {0, 0, 0, 0, 0, 0, 0, 0};
+    Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     GlobalScene mem{sc.nodes, sc.tris};
     for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (uint64_t)gridDim.x * kBlock) {
         const double* in = pairs + 6 * r;
-        out[r] = visible<false>(mem, mk(in[0], in[1], in[2]), mk(in[3], in[4], in[5]), c) ? 1 : 0;
+        out[r] = visible<kStatsOff>(mem, mk(in[0], in[1], in[2]), mk(in[3], in[4], in[5]), c) ? 1 : 0;
     }
 }
 
@@ -214,30 +214,37 @@ static size_t scene_lds_bytes(const SceneDev& sc) {
 bool scene_fits_lds(const SceneDev& sc) { return scene_lds_bytes(sc) <= kSceneLdsLimit; }
 
 // Resident workgroups per CU of the render kernel variant a launch would pick (sizes the persistent grid).
-hipError_t render_blocks_per_cu(const SceneDev& sc, bool stats, int* out) {
+template <int STATS, bool LDS>
+static hipError_t occupancy_of(size_t shmem, int* n) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, render_kernel<STATS, LDS>, kBlock, shmem);
+}
+
+hipError_t render_blocks_per_cu(const SceneDev& sc, int stats_mode, int* out) {
     const bool lds = scene_fits_lds(sc);
     const size_t shmem = sizeof(double) * kBlock * 6 + (lds ? scene_lds_bytes(sc) : 0);
     int n = 0;
     hipError_t e;
-    if (stats) e = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true>, kBlock, shmem)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false>, kBlock, shmem);
-    else e = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, true>, kBlock, shmem)
-                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false>, kBlock, shmem);
+    if (stats_mode == kStatsReference) e = lds ? occupancy_of<kStatsReference, true>(shmem, &n) : occupancy_of<kStatsReference, false>(shmem, &n);
+    else if (stats_mode == kStatsWork) e = lds ? occupancy_of<kStatsWork, true>(shmem, &n) : occupancy_of<kStatsWork, false>(shmem, &n);
+    else e = lds ? occupancy_of<kStatsOff, true>(shmem, &n) : occupancy_of<kStatsOff, false>(shmem, &n);
     *out = n < 1 ? 1 : n;
     return e;
 }
 
-hipError_t launch_render(const SceneDev& sc, const GpuCamera& cam, const RenderLaunch& rl, int grid_blocks, bool stats,
+hipError_t launch_render(const SceneDev& sc, const GpuCamera& cam, const RenderLaunch& rl, int grid_blocks, int stats_mode,
                          hipStream_t stream) {
     const bool lds = scene_fits_lds(sc);
     size_t shmem = sizeof(double) * kBlock * 6 + (lds ? scene_lds_bytes(sc) : 0);
     dim3 grid(grid_blocks), block(kBlock);
-    if (stats) {
-        if (lds) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, shmem, stream, sc, cam, rl);
-        else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, shmem, stream, sc, cam, rl);
+    if (stats_mode == kStatsReference) {
+        if (lds) hipLaunchKernelGGL((render_kernel<kStatsReference, true>), grid, block, shmem, stream, sc, cam, rl);
+        else hipLaunchKernelGGL((render_kernel<kStatsReference, false>), grid, block, shmem, stream, sc, cam, rl);
+    } else if (stats_mode == kStatsWork) {
+        if (lds) hipLaunchKernelGGL((render_kernel<kStatsWork, true>), grid, block, shmem, stream, sc, cam, rl);
+        else hipLaunchKernelGGL((render_kernel<kStatsWork, false>), grid, block, shmem, stream, sc, cam, rl);
     } else {
-        if (lds) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, shmem, stream, sc, cam, rl);
-        else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, shmem, stream, sc, cam, rl);
+        if (lds) hipLaunchKernelGGL((render_kernel<kStatsOff, true>), grid, block, shmem, stream, sc, cam, rl);
+        else hipLaunchKernelGGL((render_kernel<kStatsOff, false>), grid, block, shmem, stream, sc, cam, rl);
     }
     return hipGetLastError();
 }
@@ -251,11 +258,11 @@ hipError_t launch_trace_closest(const SceneDev& sc, const double* d_rays, uint64
     if (blocks > 4096) blocks = 4096;
     dim3 grid((unsigned)blocks), block(kBlock);
     if (d_stats) {
-        if (lds) hipLaunchKernelGGL((trace_closest_kernel<true, true>), grid, block, shmem, stream, sc, d_rays, n, d_hits, d_stats);
-        else hipLaunchKernelGGL((trace_closest_kernel<true, false>), grid, block, shmem, stream, sc, d_rays, n, d_hits, d_stats);
+        if (lds) hipLaunchKernelGGL((trace_closest_kernel<kStatsReference, true>), grid, block, shmem, stream, sc, d_rays, n, d_hits, d_stats);
+        else hipLaunchKernelGGL((trace_closest_kernel<kStatsReference, false>), grid, block, shmem, stream, sc, d_rays, n, d_hits, d_stats);
     } else {
-        if (lds) hipLaunchKernelGGL((trace_closest_kernel<false, true>), grid, block, shmem, stream, sc, d_rays, n, d_hits, d_stats);
-        else hipLaunchKernelGGL((trace_closest_kernel<false, false>), grid, block, shmem, stream, sc, d_rays, n, d_hits, d_stats);
+        if (lds) hipLaunchKernelGGL((trace_closest_kernel<kStatsOff, true>), grid, block, shmem, stream, sc, d_rays, n, d_hits, d_stats);
+        else hipLaunchKernelGGL((trace_closest_kernel<kStatsOff, false>), grid, block, shmem, stream, sc, d_rays, n, d_hits, d_stats);
     }
     return hipGetLastError();
 }

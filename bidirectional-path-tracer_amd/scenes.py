@@ -254,3 +254,105 @@ def no_light_room(image_width: int = 24, samples_per_pixel: int = 4, max_depth: 
                       max_depth=max_depth, background=(0.7, 0.8, 1.0), vfov=50.0, lookfrom=(0, 3, -8),
                       lookat=(0, 1, 0), vup=(0, 1, 0), file_name="nolight.png")
     return s
+
+
+# ------------------------------------------------------------------------------- stand-ins for the shipped scenes
+def _lathe(profile, segments):
+    """Triangles (numpy, M x 9) of the surface of revolution of the (r, y) polyline `profile`
+    around the y axis.  Profile points with r == 0 produce single triangles (no degenerate ones)."""
+    ang = np.linspace(0.0, 2.0 * math.pi, segments + 1)
+    ca, sa = np.cos(ang), np.sin(ang)
+    ca[-1], sa[-1] = ca[0], sa[0]                 # close the seam exactly
+    tris = []
+    for (r0, y0), (r1, y1) in zip(profile[:-1], profile[1:]):
+        for k in range(segments):
+            a0 = (r0 * ca[k], y0, r0 * sa[k]); a1 = (r0 * ca[k + 1], y0, r0 * sa[k + 1])
+            b0 = (r1 * ca[k], y1, r1 * sa[k]); b1 = (r1 * ca[k + 1], y1, r1 * sa[k + 1])
+            if r0 > 0:
+                tris.append(a0 + b0 + a1)
+            if r1 > 0:
+                tris.append(a1 + b0 + b1)
+    return np.array(tris, dtype=np.float64)
+
+
+def _orient_outward(tris):
+    """Flip the winding of a closed mesh if its signed volume is negative, so that cross(e1, e2)
+    points out of the enclosed medium (dielectric::scatter picks 1/ior on front faces)."""
+    v0, v1, v2 = tris[:, 0:3], tris[:, 3:6], tris[:, 6:9]
+    vol = np.einsum("ij,ij->i", v0, np.cross(v1, v2)).sum() / 6.0
+    if vol < 0:
+        tris = np.concatenate([v0, v2, v1], axis=1)
+    return tris
+
+
+def _add_mesh(scene: FlatScene, tris, mat: int, offset=(0.0, 0.0, 0.0)):
+    off = np.array(offset, dtype=np.float64)
+    for t in tris:
+        scene.add_triangle(t[0:3] + off, t[3:6] + off, t[6:9] + off, mat)
+
+
+def glass_of_water_standin(image_width: int = 1920, image_height: int = 1080, samples_per_pixel: int = 1024,
+                           max_depth: int = 12, detail: float = 1.0) -> FlatScene:
+    """Procedural stand-in for /root/reference/scenes/glass-of-water.yaml, whose OBJ meshes
+    (scenes/data/glass-of-water/models/Mesh0xx.obj) are not part of the reference checkout.
+
+    Camera, material table and the area-light quad are the YAML's values (glass-of-water.yaml:1-46,
+    128-136); the geometry is a lathe-turned glass holding water with ice blocks (two of them with
+    enclosed 'AirIce' pockets), on a metal floor in front of a curved metal backdrop - the same
+    material mix (every surface except the light is a delta material) at a comparable triangle
+    count (~45 k at detail 1)."""
+    s = FlatScene()
+    c = 147.0 / 255.0                                             # the YAML's [147,147,147] after 0-255 scaling
+    backdrop = s.add_material(Material(METAL, (147 * (1.0 / 255.0),) * 3, fuzz=0.1))
+    floor = s.add_material(Material(METAL, (147 * (1.0 / 255.0),) * 3, fuzz=0.1))
+    water = s.add_material(Material(DIELECTRIC, ior=1.33))
+    ice = s.add_material(Material(DIELECTRIC, ior=1.31))
+    glass = s.add_material(Material(DIELECTRIC, ior=1.5))
+    air_ice = s.add_material(Material(DIELECTRIC, ior=0.763))
+    light = s.add_material(Material(DIFFUSE_LIGHT, (15.9155, 27.0563, 31.831)))
+    del c
+
+    seg = max(16, int(256 * detail))
+    steps = max(4, int(40 * detail))
+    # glass: outer wall up, rim, inner wall down, thick base (closed profile from the axis back to the axis)
+    outer = [(2.0 + 0.45 * (k / steps) ** 1.5, 0.02 + 6.4 * k / steps) for k in range(steps + 1)]
+    inner = [(r - 0.16, y) for r, y in reversed(outer) if y >= 0.55]
+    prof = [(0.0, 0.02)] + outer + [(outer[-1][0] - 0.08, outer[-1][1] + 0.04)] + inner + [(0.0, inner[-1][1])]
+    _add_mesh(s, _orient_outward(_lathe(prof, seg)), glass)
+    # water body just inside the inner wall, flat surface at y = 4.4
+    wsteps = max(3, int(24 * detail))
+    y_lo, y_hi = inner[-1][1] + 0.01, 4.4
+    rad = lambda y: 2.0 + 0.45 * ((y - 0.02) / 6.4) ** 1.5 - 0.16 - 0.01
+    wprof = [(0.0, y_lo)] + [(rad(y_lo + (y_hi - y_lo) * k / wsteps), y_lo + (y_hi - y_lo) * k / wsteps)
+                             for k in range(wsteps + 1)] + [(0.0, y_hi)]
+    _add_mesh(s, _orient_outward(_lathe(wprof, seg)), water)
+    # ice blocks floating in the water, two with air pockets inside
+    add_box_triangles(s, (-0.6, 0.0, -0.6), (0.6, 1.2, 0.6), ice, 25.0, (-0.75, 3.7, 0.3))
+    add_box_triangles(s, (-0.55, 0.0, -0.55), (0.55, 1.1, 0.55), ice, -40.0, (0.8, 3.6, -0.4))
+    add_box_triangles(s, (-0.5, 0.0, -0.5), (0.5, 1.0, 0.5), ice, 10.0, (0.1, 3.9, 0.9))
+    add_box_triangles(s, (-0.2, 0.0, -0.2), (0.2, 0.4, 0.2), air_ice, 25.0, (-0.75, 4.1, 0.3))
+    add_box_triangles(s, (-0.15, 0.0, -0.15), (0.15, 0.3, 0.15), air_ice, -40.0, (0.8, 4.0, -0.4))
+    # floor and curved backdrop (a swept quarter cylinder), both metal
+    add_quad_triangles(s, (-40.0, 0.0, 30.0), (80.0, 0.0, 0.0), (0.0, 0.0, -42.0), floor)
+    bseg = max(8, int(48 * detail))
+    bx = max(4, int(24 * detail))
+    R = 12.0
+    for k in range(bseg):
+        t0, t1 = 0.5 * math.pi * k / bseg, 0.5 * math.pi * (k + 1) / bseg
+        z0, y0 = -12.0 - R * math.sin(t0), R - R * math.cos(t0)
+        z1, y1 = -12.0 - R * math.sin(t1), R - R * math.cos(t1)
+        for j in range(bx):
+            xa, xb = -40.0 + 80.0 * j / bx, -40.0 + 80.0 * (j + 1) / bx
+            add_quad_triangles(s, (xa, y0, z0), (xb - xa, 0.0, 0.0), (0.0, y1 - y0, z1 - z0), backdrop)
+    add_quad_triangles(s, (-40.0, R, -12.0 - R), (80.0, 0.0, 0.0), (0.0, 30.0, 0.0), backdrop)
+    # the YAML's area light, as its two indexed triangles
+    lv = [(-2.53848244, 12.39156476, 24.58024509), (2.46151756, 12.39156524, 24.58024491),
+          (2.46151804, 8.57023524, 27.80475491), (-2.53848196, 8.57023476, 27.80475509)]
+    s.add_triangle(lv[0], lv[1], lv[2], light)
+    s.add_triangle(lv[0], lv[2], lv[3], light)
+    s.camera = Camera(aspect_ratio=float(image_width) / float(image_height), image_width=image_width,
+                      samples_per_pixel=samples_per_pixel, max_depth=max_depth, background=(0.0, 0.0, 0.0), vfov=35.0,
+                      lookfrom=(-0.08935849368572235, 2.694121837615967, 25.672550201416016),
+                      lookat=(0.006514795124530792, 3.1010689735412598, 0.010185359977185726), vup=(0.0, 1.0, 0.0),
+                      defocus_angle=0.0, focus_dist=10.0, file_name="glass_of_water.png")
+    return s

@@ -95,7 +95,12 @@ typedef struct bdpt_render_params {
     int32_t flags;              /* BDPT_RENDER_* */
 } bdpt_render_params;
 
-#define BDPT_RENDER_COUNT_STATS 1   /* also accumulate bdpt_stats (slower) */
+#define BDPT_RENDER_COUNT_STATS 1   /* accumulate bdpt_stats with the reference's BvhStats semantics: visibility queries
+                                       run the reference's full closest-hit traversal (camera.h:437) so every counter
+                                       equals what the CPU renderer prints (slower; for verification) */
+#define BDPT_RENDER_COUNT_WORK 2    /* accumulate bdpt_stats of the work the production path does (visibility queries
+                                       stop at the first hit); ignored when BDPT_RENDER_COUNT_STATS is set */
+#define BDPT_RENDER_TIME_KERNEL 4   /* bracket the render kernel with HIP events on its stream (bdpt_render_get_kernel_ms) */
 
 /* Work counters.  The first six have the meaning of the reference's BvhStats
  * (src/core/stats.h:8-16); a triangle referenced twice by a one-triangle BVH node is
@@ -111,6 +116,7 @@ typedef struct bdpt_stats {
     uint64_t connection_pairs;  /* non-delta (eye, light) vertex pairs (camera.h:441) */
     uint64_t rng_draws;
     uint64_t samples;           /* (pixel, sample) pairs rendered */
+    uint64_t path_vertices;     /* non-delta path vertices kept for the connection step (camera.h:342-349) */
 } bdpt_stats;
 
 typedef struct bdpt_scene_info {
@@ -176,8 +182,11 @@ int bdpt_render(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
 /* Same, framebuffer in device memory; returns after enqueueing on `stream` (hipStream_t or NULL). */
 int bdpt_render_device(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam,
                        const bdpt_render_params* params, void* d_framebuffer, void* stream);
-/* Counters of the last bdpt_render_device call that had BDPT_RENDER_COUNT_STATS set (synchronises). */
+/* Counters of the last bdpt_render_device call that requested them (synchronises). */
 int bdpt_render_get_stats(bdpt_context* ctx, bdpt_stats* out);
+/* Device time of the render kernel of the last call that had BDPT_RENDER_TIME_KERNEL set, from HIP
+ * events recorded around the launch on the launch's own stream (waits for the kernel). */
+int bdpt_render_get_kernel_ms(bdpt_context* ctx, float* out_ms);
 
 /* colors_to_rgb8(), src/image/wpng.h:14-35: sum/spp -> clamp [0,0.999] -> sqrt -> *256 -> u8.
  * NaN (undefined behaviour in the reference) maps to 0. */

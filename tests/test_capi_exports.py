@@ -32,7 +32,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(capi.CameraPublic) == 16 * 8 + 16
     assert C.sizeof(capi.CameraState) == 15 * 8 + 16
     assert C.sizeof(capi.RenderParams) == 8 + 8 * 4
-    assert C.sizeof(capi.Stats) == 80
+    assert C.sizeof(capi.Stats) == 88
     assert C.sizeof(capi.SceneInfo) == 32
 
 
