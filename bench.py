@@ -153,6 +153,7 @@ def main():
     import torch
     import torch.distributed as dist
     capi = importlib.import_module(PKG + ".capi")
+    distributed = importlib.import_module(PKG + ".distributed")
 
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -165,18 +166,14 @@ def main():
     W, H, spp_used, depth = cam.image_width, cam.image_height, cam.sqrt_spp ** 2, cam.max_depth
     fb = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    shard = (rank, world, args.shard_rows)
-
     kernel_ms = []
 
     def step(timed):
-        if world > 1:
-            fb.zero_()
-        scene.render_device(cam, fb.data_ptr(), seed=args.seed, shard=shard, stream=stream, time_kernel=timed)
-        if timed:
-            kernel_ms.append(scene.last_kernel_ms())       # waits for the kernel's stop event
-        if world > 1:
-            dist.all_reduce(fb, op=dist.ReduceOp.SUM)
+        def render_shard(buf, shard):
+            scene.render_device(cam, buf.data_ptr(), seed=args.seed, shard=shard, stream=stream, time_kernel=timed)
+            if timed:
+                kernel_ms.append(scene.last_kernel_ms())   # waits for the kernel's stop event
+        distributed.render_frame(render_shard, fb, rank, world, args.shard_rows, dist)
 
     for _ in range(args.warmup):
         step(False)

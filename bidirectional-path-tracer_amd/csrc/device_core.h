@@ -290,6 +290,79 @@ BDPT_DEV V3 evaluate_bsdf(const GpuMaterial& m) {
     return mk(0, 0, 0);
 }
 
+// One iteration of the loop of camera::trace_path (src/camera.h:342-368) after a hit was found:
+// builds the path vertex, evaluates emission, samples the material.
+struct Bounce {
+    bool keep;            // non-delta vertex: goes into the vertex store (camera.h:441 drops delta ones)
+    Vertex vx;
+    bool emitted;         // EYE only: non-delta emissive vertex, camera.h:306-309
+    V3 emitted_term;
+    bool cont;            // path continues with (o, d, T)
+    V3 o, d, T;
+};
+
+template <bool EYE>
+BDPT_DEV void shade_bounce(const SceneDev& sc, V3 o, V3 d, const HitLite& h, V3 throughput, Rng& rng, Bounce& out) {
+    const GpuTriAux ax = sc.aux[h.tri];
+    const int32_t mat_id = sc.tris[h.tri].material;
+    const GpuMaterial m = sc.mats[mat_id];
+    V3 p = add(o, scl(h.t, d));                                           // ray.h:21-23
+    V3 outward = ld3(ax.normal);
+    bool front_face = dot(d, outward) < 0;                                // hittable.h:20-26
+    V3 normal = front_face ? outward : neg(outward);
+
+    out.keep = (m.type == 0 || m.type == 3);
+    out.vx.p = p; out.vx.n = normal; out.vx.T = throughput;
+    out.vx.info = (uint32_t)mat_id | (m.type == 3 ? kVtxIsLight : 0u) | (front_face ? kVtxFrontFace : 0u);
+    out.emitted = false;
+    out.emitted_term = mk(0, 0, 0);
+    out.cont = false;
+    out.o = p; out.d = d; out.T = throughput;
+
+    if (m.type == 3) {                                                    // diffuse_light: emits, never scatters (material.h:26-28)
+        if (EYE && front_face) {
+            V3 e = ld3(m.rgb);
+            if (len2(e) > 0) { out.emitted_term = mulv(throughput, e); out.emitted = true; }
+        }
+        return;
+    }
+    if (m.type == 1) {                                                    // metal, material.h:73-83, camera.h:355-359
+        V3 reflected = reflect(d, normal);
+        reflected = add(unit(reflected), scl(m.fuzz, random_unit_vector(rng)));
+        out.T = mulv(throughput, ld3(m.rgb));
+        out.d = reflected;
+        out.cont = true;
+        return;
+    }
+    if (m.type == 2) {                                                    // dielectric, material.h:96-116
+        double ri = front_face ? (1.0 / m.ior) : m.ior;
+        V3 unit_direction = unit(d);
+        double cos_theta = __builtin_fmin(dot(neg(unit_direction), normal), 1.0);
+        double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = ri * sin_theta > 1.0;
+        V3 direction;
+        if (cannot_refract || reflectance(cos_theta, ri) > rng.next())   // no draw on total internal reflection
+            direction = reflect(unit_direction, normal);
+        else
+            direction = refract(unit_direction, normal, ri);
+        out.T = mulv(throughput, mk(1.0, 1.0, 1.0));
+        out.d = direction;
+        out.cont = true;
+        return;
+    }
+    // lambertian, material.h:47-58 + pdf.h:32-47 + camera.h:361-368
+    V3 w;
+    V3 scattered = onb_transform(normal, random_cosine_direction(rng), w);
+    V3 su = unit(scattered);
+    double pdf_value = __builtin_fmax(0.0, dot(su, w) / kPi);
+    if (pdf_value <= 0) return;
+    double cos_theta = dot(normal, su);
+    double scattering_pdf = cos_theta < 0 ? 0 : cos_theta / kPi;
+    out.T = divs(scl(scattering_pdf, mulv(throughput, ld3(m.rgb))), pdf_value);
+    out.d = scattered;
+    out.cont = true;
+}
+
 // camera::trace_path, src/camera.h:325-370.  Stores the non-delta vertices into `store` starting
 // at slot `slot0`; returns how many were stored.  `n_hits` counts ALL vertices (delta ones too).
 // Eye subpaths (EYE) also return the background term (camera.h:337-338) and the emission term of
@@ -309,61 +382,16 @@ BDPT_DEV int trace_path(const Mem& mem, const SceneDev& sc, const GpuCamera& cam
             break;
         }
         n_hits++;
-        const GpuTriAux ax = sc.aux[h.tri];
-        const int32_t mat_id = mem.tri(h.tri).material;
-        const GpuMaterial m = sc.mats[mat_id];
-        V3 p = add(o, scl(h.t, d));                                           // ray.h:21-23
-        V3 outward = ld3(ax.normal);
-        bool front_face = dot(d, outward) < 0;                                // hittable.h:20-26
-        V3 normal = front_face ? outward : neg(outward);
-
-        if (m.type == 0 || m.type == 3) {                                     // non-delta: keep for the connections
-            Vertex vx;
-            vx.p = p; vx.n = normal; vx.T = throughput;
-            vx.info = (uint32_t)mat_id | (m.type == 3 ? kVtxIsLight : 0u) | (front_face ? kVtxFrontFace : 0u);
-            store.put(slot0 + stored, vx);
+        Bounce b;
+        shade_bounce<EYE>(sc, o, d, h, throughput, rng, b);
+        if (b.keep) {
+            store.put(slot0 + stored, b.vx);
             stored++;
             if (STATS) c.vertices++;
         }
-        if (m.type == 3) {                                                    // diffuse_light: emits, never scatters
-            if (EYE && front_face) {
-                V3 e = ld3(m.rgb);
-                if (len2(e) > 0) { emitted_term = mulv(throughput, e); has_emitted = true; }
-            }
-            break;
-        }
-        if (m.type == 1) {                                                    // metal, material.h:73-83
-            V3 reflected = reflect(d, normal);
-            reflected = add(unit(reflected), scl(m.fuzz, random_unit_vector(rng)));
-            throughput = mulv(throughput, ld3(m.rgb));
-            o = p; d = reflected;
-            continue;
-        }
-        if (m.type == 2) {                                                    // dielectric, material.h:96-116
-            double ri = front_face ? (1.0 / m.ior) : m.ior;
-            V3 unit_direction = unit(d);
-            double cos_theta = __builtin_fmin(dot(neg(unit_direction), normal), 1.0);
-            double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
-            bool cannot_refract = ri * sin_theta > 1.0;
-            V3 direction;
-            if (cannot_refract || reflectance(cos_theta, ri) > rng.next())
-                direction = reflect(unit_direction, normal);
-            else
-                direction = refract(unit_direction, normal, ri);
-            throughput = mulv(throughput, mk(1.0, 1.0, 1.0));
-            o = p; d = direction;
-            continue;
-        }
-        // lambertian, material.h:47-58 + pdf.h:32-47 + camera.h:361-368
-        V3 w;
-        V3 scattered = onb_transform(normal, random_cosine_direction(rng), w);
-        V3 su = unit(scattered);
-        double pdf_value = __builtin_fmax(0.0, dot(su, w) / kPi);
-        if (pdf_value <= 0) break;
-        double cos_theta = dot(normal, su);
-        double scattering_pdf = cos_theta < 0 ? 0 : cos_theta / kPi;
-        throughput = divs(scl(scattering_pdf, mulv(throughput, ld3(m.rgb))), pdf_value);
-        o = p; d = scattered;
+        if (EYE && b.emitted) { emitted_term = b.emitted_term; has_emitted = true; }
+        if (!b.cont) break;
+        o = b.o; d = b.d; throughput = b.T;
     }
     return stored;
 }
@@ -380,29 +408,110 @@ BDPT_DEV int pick_light(const SceneDev& sc, double pick) {
     return lo;
 }
 
-// camera::connect_vertices, src/camera.h:440-475 (both vertices non-delta)
-template <int STATS, class Mem>
-BDPT_DEV V3 connect(const Mem& mem, const SceneDev& sc, const Vertex& cv, const Vertex& lv, Counters& c) {
-    if (STATS) c.pairs++;
+// camera::connect_vertices, src/camera.h:440-475, in two halves around the visibility query.
+// Geometry half (camera.h:444-453 + the ray set-up of camera::visible, camera.h:426-436): false when the
+// pair contributes nothing before any ray is needed; otherwise the shadow ray and the cosine / distance terms.
+struct PairGeom {
+    V3 origin, dir_unit;
+    double max_t, cos_cam, cos_light, dist2;
+};
+BDPT_DEV bool pair_geometry(const Vertex& cv, const Vertex& lv, PairGeom& g) {
     V3 dir = sub(lv.p, cv.p);
-    double dist2 = len2(dir);
-    if (dist2 <= 0) return mk(0, 0, 0);
-    V3 dir_unit = unit(dir);
-    double cos_cam = __builtin_fabs(dot(cv.n, dir_unit));
-    double cos_light = __builtin_fabs(dot(lv.n, neg(dir_unit)));
-    if (cos_cam <= 0 || cos_light <= 0) return mk(0, 0, 0);
-    if (!visible<STATS>(mem, cv.p, lv.p, c)) return mk(0, 0, 0);
-    V3 f_cam = evaluate_bsdf(sc.mats[cv.info & kVtxMatMask]);
-    if (len2(f_cam) <= 0) return mk(0, 0, 0);
-    V3 f_light;
+    g.dist2 = len2(dir);
+    if (g.dist2 <= 0) return false;
+    g.dir_unit = unit(dir);                                   // == dir / dist of camera::visible, bit for bit
+    g.cos_cam = __builtin_fabs(dot(cv.n, g.dir_unit));
+    g.cos_light = __builtin_fabs(dot(lv.n, neg(g.dir_unit)));
+    if (g.cos_cam <= 0 || g.cos_light <= 0) return false;
+    double dist = __builtin_sqrt(g.dist2);
+    if (dist <= 0) return false;
+    g.origin = add(cv.p, scl(0.001, g.dir_unit));
+    g.max_t = dist - 0.001;
+    if (g.max_t <= 0) return false;
+    return true;
+}
+// BSDF / emission factors of the two end points (camera.h:458-469); false when either is zero
+BDPT_DEV bool pair_factors(const SceneDev& sc, const Vertex& cv, const Vertex& lv, V3& f_cam, V3& f_light) {
+    f_cam = evaluate_bsdf(sc.mats[cv.info & kVtxMatMask]);
+    if (len2(f_cam) <= 0) return false;
     const GpuMaterial lm = sc.mats[lv.info & kVtxMatMask];
     if (lv.info & kVtxIsLight) f_light = (lv.info & kVtxFrontFace) ? ld3(lm.rgb) : mk(0, 0, 0);
     else f_light = evaluate_bsdf(lm);
-    if (len2(f_light) <= 0) return mk(0, 0, 0);
+    return len2(f_light) > 0;
+}
+// camera.h:471-474
+BDPT_DEV V3 pair_contribution(const Vertex& cv, const Vertex& lv, const PairGeom& g, V3 f_cam, V3 f_light) {
     V3 contrib = mulv(cv.T, f_cam);
     contrib = mulv(mulv(contrib, lv.T), f_light);
-    contrib = divs(scl(cos_cam * cos_light, contrib), dist2);
-    return contrib;
+    return divs(scl(g.cos_cam * g.cos_light, contrib), g.dist2);
+}
+
+template <int STATS, class Mem>
+BDPT_DEV V3 connect(const Mem& mem, const SceneDev& sc, const Vertex& cv, const Vertex& lv, Counters& c) {
+    if (STATS) c.pairs++;
+    PairGeom g;
+    if (!pair_geometry(cv, lv, g)) return mk(0, 0, 0);
+    if (STATS) c.shadow_rays++;
+    HitLite tmp;
+    if (walk<STATS, STATS != kStatsReference>(mem, g.origin, g.dir_unit, 0.001, g.max_t, tmp, c)) return mk(0, 0, 0);
+    V3 f_cam, f_light;
+    if (!pair_factors(sc, cv, lv, f_cam, f_light)) return mk(0, 0, 0);
+    return pair_contribution(cv, lv, g, f_cam, f_light);
+}
+
+// camera::get_ray, src/camera.h:199-223 (defocus disabled): three draws, the third (ray_time) unused
+BDPT_DEV void camera_ray(const GpuCamera& cam, int i, int j, int s_i, int s_j, Rng& rng, V3& origin, V3& dir) {
+    double px = ((s_i + rng.next()) * cam.recip_sqrt_spp) - 0.5;
+    double py = ((s_j + rng.next()) * cam.recip_sqrt_spp) - 0.5;
+    origin = ld3(cam.center);
+    V3 pixel_sample = add(add(ld3(cam.pixel00), scl(i + px, ld3(cam.du))), scl(j + py, ld3(cam.dv)));
+    dir = sub(pixel_sample, origin);
+    (void)rng.next();                                                          // ray_time, camera.h:210
+}
+
+// First half of camera::build_light_path, src/camera.h:378-415: the emitter vertex and the first
+// light ray.  `valid` is build_light_path's return value; `has_ray` is false when the sampled
+// direction is not above the surface (camera.h:410-411) or no bounce is left (depth - 1 == 0).
+struct Emitter {
+    bool valid, has_ray;
+    Vertex ev;
+    V3 o, d, T;
+};
+BDPT_DEV void sample_emitter(const SceneDev& sc, int depth, Rng& rng, Emitter& e) {
+    e.valid = false;
+    e.has_ray = false;
+    if (!(depth > 0 && sc.n_lights > 0 && sc.light_total_area > 0.0)) return;     // camera.h:378-379, triangle.h:200-208
+    double pick = rng.next(0.0, sc.light_total_area);
+    const int li = pick_light(sc, pick);
+    const int32_t tri_id = (int32_t)sc.light_tris[li];
+    double u = rng.next();
+    double v = rng.next();
+    if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
+    const GpuTri tr = sc.tris[tri_id];
+    const GpuTriAux ax = sc.aux[tri_id];
+    V3 position = add(add(ld3(tr.v0), scl(u, ld3(tr.e1))), scl(v, ld3(tr.e2)));
+    V3 normal = ld3(ax.normal);
+    const GpuMaterial m = sc.mats[tr.material];
+    V3 emission = (m.type == 3) ? ld3(m.rgb) : mk(0, 0, 0);                // front_face = true (camera.h:389)
+    if (!(len2(emission) > 0)) return;                                     // camera.h:395-396
+    e.valid = true;
+    double pdf = 1.0 / sc.light_total_area;
+    double pm = (pdf < 1e-8) ? 1e-8 : pdf;                                 // std::max(sample.pdf, 1e-8)
+    e.ev.p = position; e.ev.n = normal;
+    e.ev.T = divs(mk(1.0, 1.0, 1.0), pm);
+    e.ev.info = (uint32_t)tr.material | kVtxIsLight | kVtxFrontFace;
+    V3 w;
+    V3 ldir = onb_transform(normal, random_cosine_direction(rng), w);      // camera.h:420-423
+    V3 dir_unit = unit(ldir);
+    double dt = dot(normal, dir_unit);
+    double cos_theta = (0.0 < dt) ? dt : 0.0;                              // std::max(0.0, dot)
+    if (!(cos_theta > 0)) return;
+    double q = cos_theta / kPi;
+    double pdf_dir = (q < 1e-8) ? 1e-8 : q;                                // std::max(cos/pi, 1e-8)
+    e.T = scl(cos_theta / pdf_dir, mulv(e.ev.T, emission));
+    e.o = add(position, scl(0.001, normal));
+    e.d = dir_unit;
+    e.has_ray = true;
 }
 
 // camera::get_ray + ray_color -> bidirectional_color for one sample: src/camera.h:199-223,294-323,372-418
@@ -413,14 +522,8 @@ BDPT_DEV V3 sample_radiance(const Mem& mem, const SceneDev& sc, const GpuCamera&
     rng.key = stream_key(seed, (uint64_t)j * (uint64_t)cam.width + (uint64_t)i, (uint64_t)s_j * cam.sqrt_spp + s_i);
     rng.counter = 0;
     const int depth = cam.max_depth;
-
-    // get_ray, camera.h:199-223
-    double px = ((s_i + rng.next()) * cam.recip_sqrt_spp) - 0.5;
-    double py = ((s_j + rng.next()) * cam.recip_sqrt_spp) - 0.5;
-    V3 center = ld3(cam.center);
-    V3 pixel_sample = add(add(ld3(cam.pixel00), scl(i + px, ld3(cam.du))), scl(j + py, ld3(cam.dv)));
-    V3 dir = sub(pixel_sample, center);
-    (void)rng.next();                                                          // ray_time, camera.h:210
+    V3 center, dir;
+    camera_ray(cam, i, j, s_i, s_j, rng, center, dir);
 
     // eye subpath, camera.h:300-309
     V3 background_contrib = mk(0, 0, 0), emitted_term = mk(0, 0, 0);
@@ -433,53 +536,24 @@ BDPT_DEV V3 sample_radiance(const Mem& mem, const SceneDev& sc, const GpuCamera&
 
     // light subpath, camera.h:372-418
     int n_light = 0;
-    bool have_light_path = false;
-    if (depth > 0 && sc.n_lights > 0 && sc.light_total_area > 0.0) {
-        double pick = rng.next(0.0, sc.light_total_area);
-        const int li = pick_light(sc, pick);
-        const int32_t tri_id = (int32_t)sc.light_tris[li];
-        double u = rng.next();
-        double v = rng.next();
-        if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
-        const GpuTri tr = mem.tri(tri_id);
-        const GpuTriAux ax = sc.aux[tri_id];
-        V3 position = add(add(ld3(tr.v0), scl(u, ld3(tr.e1))), scl(v, ld3(tr.e2)));
-        V3 normal = ld3(ax.normal);
-        const GpuMaterial m = sc.mats[tr.material];
-        V3 emission = (m.type == 3) ? ld3(m.rgb) : mk(0, 0, 0);                // front_face = true (camera.h:389)
-        if (len2(emission) > 0) {
-            have_light_path = true;
-            double pdf = 1.0 / sc.light_total_area;
-            double pm = (pdf < 1e-8) ? 1e-8 : pdf;                             // std::max(sample.pdf, 1e-8)
-            Vertex ev;
-            ev.p = position; ev.n = normal;
-            ev.T = divs(mk(1.0, 1.0, 1.0), pm);
-            ev.info = (uint32_t)tr.material | kVtxIsLight | kVtxFrontFace;
-            store.put(depth, ev);
-            if (STATS) c.vertices++;
-            n_light = 1;
-            light_hits = 1;
-            V3 w;
-            V3 ldir = onb_transform(normal, random_cosine_direction(rng), w);  // camera.h:420-423
-            V3 dir_unit = unit(ldir);
-            double dt = dot(normal, dir_unit);
-            double cos_theta = (0.0 < dt) ? dt : 0.0;                          // std::max(0.0, dot)
-            if (cos_theta > 0) {
-                double q = cos_theta / kPi;
-                double pdf_dir = (q < 1e-8) ? 1e-8 : q;                        // std::max(cos/pi, 1e-8)
-                V3 throughput = scl(cos_theta / pdf_dir, mulv(ev.T, emission));
-                V3 lo = add(position, scl(0.001, normal));
-                V3 dummy_bg = mk(0, 0, 0), dummy_e = mk(0, 0, 0);
-                bool dummy_flag = false;
-                int lh = 0;
-                n_light += trace_path<STATS, false>(mem, sc, cam, lo, dir_unit, depth - 1, throughput, rng, store,
-                                                    depth + 1, c, lh, dummy_bg, dummy_e, dummy_flag);
-                light_hits += lh;
-            }
+    Emitter em;
+    sample_emitter(sc, depth, rng, em);
+    if (em.valid) {
+        store.put(depth, em.ev);
+        if (STATS) c.vertices++;
+        n_light = 1;
+        light_hits = 1;
+        if (em.has_ray) {
+            V3 dummy_bg = mk(0, 0, 0), dummy_e = mk(0, 0, 0);
+            bool dummy_flag = false;
+            int lh = 0;
+            n_light += trace_path<STATS, false>(mem, sc, cam, em.o, em.d, depth - 1, em.T, rng, store, depth + 1, c, lh,
+                                                dummy_bg, dummy_e, dummy_flag);
+            light_hits += lh;
         }
     }
     draws = rng.counter;
-    if (!have_light_path) return result;
+    if (!em.valid) return result;
 
     // connections, camera.h:316-320.  The reference adds a (possibly zero) colour for every pair;
     // adding +0 only matters for a -0 accumulator, which the first add below normalises.
