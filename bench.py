@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--workload", default="glass-of-water-1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--shard-rows", type=int, default=4, help="height of the row bands dealt round-robin to the GPUs")
+    ap.add_argument("--megakernel", action="store_true", help="time the single persistent kernel instead of the wavefront pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -170,7 +171,8 @@ def main():
 
     def step(timed):
         def render_shard(buf, shard):
-            scene.render_device(cam, buf.data_ptr(), seed=args.seed, shard=shard, stream=stream, time_kernel=timed)
+            scene.render_device(cam, buf.data_ptr(), seed=args.seed, shard=shard, stream=stream, time_kernel=timed,
+                                megakernel=args.megakernel)
             if timed:
                 kernel_ms.append(scene.last_kernel_ms())   # waits for the kernel's stop event
         distributed.render_frame(render_shard, fb, rank, world, args.shard_rows, dist)
@@ -225,7 +227,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_roofline:
         # untimed counting pass over every 8th row (same kernel with its work counters on)
         fb2 = torch.zeros_like(fb)
-        scene.render_device(cam, fb2.data_ptr(), seed=args.seed, shard=(0, 8, 1), want_stats="work", stream=stream)
+        scene.render_device(cam, fb2.data_ptr(), seed=args.seed, shard=(0, 8, 1), want_stats="work", stream=stream,
+                            megakernel=args.megakernel)
         st = scene.last_stats()
         frac = st.samples / float(W * H * spp_used)
         alg = (B_RAY * (st.rays_traced + st.shadow_rays) + B_NODE * st.aabb_tests + B_TRI * st.triangle_tests +
@@ -243,7 +246,8 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "kernel": "render_kernel", "kernel_ms": ms, "algorithmic_bytes_per_launch": alg,
+            "kernel": "render_kernel (single persistent kernel)" if args.megakernel else "wavefront pipeline (all kernels of one frame)",
+            "kernel_ms": ms, "algorithmic_bytes_per_launch": alg,
             "per_sample": {"trace_rays": st.rays_traced / st.samples, "shadow_rays": st.shadow_rays / st.samples,
                            "node_visits": st.aabb_tests / st.samples, "triangle_tests": st.triangle_tests / st.samples,
                            "connection_pairs": st.connection_pairs / st.samples, "rng_draws": st.rng_draws / st.samples},

@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libbdpt_amd.so")
 
 BDPT_RENDER_COUNT_STATS = 1     # counters with the reference's BvhStats semantics
 BDPT_RENDER_COUNT_WORK = 2      # counters of the work the production path does
-BDPT_RENDER_TIME_KERNEL = 4     # HIP events around the render kernel
+BDPT_RENDER_TIME_KERNEL = 4     # HIP events around the render kernels
+BDPT_RENDER_MEGAKERNEL = 8      # single persistent kernel instead of the wavefront pipeline
 
 
 class BdptError(RuntimeError):
@@ -259,16 +260,19 @@ class Scene:
         return out
 
     @staticmethod
-    def _flags(want_stats, time_kernel=False):
+    def _flags(want_stats, time_kernel=False, megakernel=False):
         """want_stats: False / True or "reference" (BvhStats semantics) / "work" (production path's own work)"""
         f = BDPT_RENDER_TIME_KERNEL if time_kernel else 0
+        if megakernel:
+            f |= BDPT_RENDER_MEGAKERNEL
         if want_stats == "work":
             f |= BDPT_RENDER_COUNT_WORK
         elif want_stats:
             f |= BDPT_RENDER_COUNT_STATS
         return f
 
-    def render(self, cam_state: CameraState, seed=0, rect=None, shard=(0, 1, 1), want_stats=False, framebuffer=None):
+    def render(self, cam_state: CameraState, seed=0, rect=None, shard=(0, 1, 1), want_stats=False, framebuffer=None,
+               megakernel=False):
         """Host-buffer render; returns the full W x H x 3 framebuffer of sums (unowned pixels keep
         the values of `framebuffer`, zeros by default) and optionally the counters."""
         W, H = cam_state.image_width, cam_state.image_height
@@ -278,20 +282,20 @@ class Scene:
         if rect is not None:
             p.x0, p.y0, p.x1, p.y1 = [int(v) for v in rect]
         p.shard_index, p.shard_count, p.shard_rows = shard
-        p.flags = self._flags(want_stats)
+        p.flags = self._flags(want_stats, megakernel=megakernel)
         st = Stats()
         _check(self.lib.bdpt_render(self.ctx.h, self.h, C.byref(cam_state), C.byref(p), _ptr(fb), C.byref(st)))
         return (fb, st) if want_stats else fb
 
     def render_device(self, cam_state: CameraState, d_framebuffer: int, seed=0, rect=None, shard=(0, 1, 1),
-                      want_stats=False, stream: int = 0, time_kernel=False):
+                      want_stats=False, stream: int = 0, time_kernel=False, megakernel=False):
         """Framebuffer already in device memory (`d_framebuffer` = device pointer, e.g. tensor.data_ptr())."""
         p = RenderParams()
         p.seed = seed
         if rect is not None:
             p.x0, p.y0, p.x1, p.y1 = [int(v) for v in rect]
         p.shard_index, p.shard_count, p.shard_rows = shard
-        p.flags = self._flags(want_stats, time_kernel)
+        p.flags = self._flags(want_stats, time_kernel, megakernel)
         _check(self.lib.bdpt_render_device(self.ctx.h, self.h, C.byref(cam_state), C.byref(p), C.c_void_p(d_framebuffer),
                                            C.c_void_p(stream)))
 

@@ -12,6 +12,7 @@
 #include "bdpt_types.h"
 #include "kernels.h"
 #include "scene_build.h"
+#include "wavefront.h"
 
 using namespace bdpt;
 
@@ -51,8 +52,11 @@ struct bdpt_context {
     uint32_t* unit_counter = nullptr;
     unsigned long long* stats = nullptr;
     bool stats_valid = false;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // bracket the render kernel on its own stream
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // bracket the render kernels on their own stream
     bool timing_valid = false;
+    // wavefront workspace (one allocation, carved into the WfBuffers arrays)
+    void* wf_blob = nullptr;
+    size_t wf_blob_bytes = 0;
 };
 
 struct bdpt_scene {
@@ -115,6 +119,179 @@ GpuCamera to_gpu_camera(const bdpt_camera_state& c) {
     return g;
 }
 
+// ---- single persistent kernel: one thread per sample does the whole of bidirectional_color
+int render_megakernel(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, uint64_t seed, int32_t n_rows,
+                      int x0, int x1, int64_t n_owned, double* d_fb, int stats_mode, hipStream_t stream) {
+    HIP_TRY(hipMemsetAsync(ctx->unit_counter, 0, sizeof(uint32_t), stream));
+    const int spp = cam->sqrt_spp * cam->sqrt_spp;
+    const int ppg = spp >= kBlock ? 1 : kBlock / spp;
+    const int64_t n_units = (n_owned + ppg - 1) / ppg;
+    if (n_units > 0x7FFFFFFF) return fail(BDPT_ERR_INVALID_ARGUMENT, "too many work units in one call");
+    // persistent grid: enough workgroups to fill the chip, never more than there is work
+    int per_cu = 1;
+    HIP_TRY(render_blocks_per_cu(scene->dev, stats_mode, &per_cu));
+    int64_t grid = (int64_t)ctx->cu_count * per_cu;
+    if (grid > n_units) grid = n_units;
+    const size_t ws_stride = (size_t)grid * kBlock;
+    const size_t slots = 2 * (size_t)(cam->max_depth > 0 ? cam->max_depth : 1);
+    int rc = ensure_vertex_ws(ctx, align256(ws_stride * slots * 10 * sizeof(double)));
+    if (rc != BDPT_OK) return rc;
+
+    RenderLaunch rl;
+    rl.seed = seed;
+    rl.rows = ctx->rows;
+    rl.n_rows = n_rows;
+    rl.x0 = x0; rl.x1 = x1;
+    rl.pixels_per_group = ppg;
+    rl.n_units = (int32_t)n_units;
+    rl.unit_counter = ctx->unit_counter;
+    rl.fb = d_fb;
+    rl.vertex_ws = ctx->vertex_ws;
+    rl.stats = stats_mode ? ctx->stats : nullptr;
+    rl.ws_stride = ws_stride;
+    HIP_TRY(launch_render(scene->dev, to_gpu_camera(*cam), rl, (int)grid, stats_mode, stream));
+    return BDPT_OK;
+}
+
+// ---- wavefront pipeline: batches of samples stream through per-stage kernels (wavefront.h)
+int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, uint64_t seed, int x0, int x1,
+                     int64_t n_owned, double* d_fb, int stats_mode, hipStream_t stream) {
+    const int depth = cam->max_depth;
+    const int64_t spp = (int64_t)cam->sqrt_spp * cam->sqrt_spp;
+    const size_t vslots = 2 * (size_t)(depth > 0 ? depth : 1);
+    const uint32_t vis_words = (uint32_t)((depth > 0 ? depth : 1) + 63) / 64;
+    const size_t shadow_per_slot = (size_t)(depth > 0 ? depth : 1);
+    // bytes of state per sample slot
+    const size_t per_slot = sizeof(double) * (6 + 3 + 3 + 3) + sizeof(uint32_t) * 6 + vslots * 10 * sizeof(double) +
+                            vis_words * sizeof(unsigned long long) + shadow_per_slot * 8 * sizeof(double);
+    const size_t budget = (size_t)16 << 30;                     // of 288 GB
+    int64_t ns_target = (int64_t)(budget / per_slot);
+    if (ns_target > ((int64_t)1 << 22)) ns_target = (int64_t)1 << 22;
+    if (spp > ns_target) return fail(BDPT_ERR_UNSUPPORTED, "samples per pixel exceed the wavefront batch capacity");
+    int64_t pixels_per_batch = ns_target / spp;
+    if (pixels_per_batch > n_owned) pixels_per_batch = n_owned;
+    const uint64_t ns = (uint64_t)(pixels_per_batch * spp);
+    const uint64_t shadow_cap = ns * shadow_per_slot;
+    const size_t n_counters = 8 + 6 * (size_t)(depth > 0 ? depth : 1);
+
+    // carve the workspace
+    size_t off = 0;
+    auto take = [&off](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+    const size_t o_ray = take(ns * 6 * 8), o_thr = take(ns * 3 * 8), o_hit = take(ns * 3 * 8), o_res = take(ns * 3 * 8);
+    const size_t o_tri = take(ns * 4), o_ctr = take(ns * 4), o_cnt = take(ns * 4);
+    const size_t o_q0 = take(ns * 4), o_q1 = take(ns * 4), o_cq = take(ns * 4);
+    const size_t o_vtx = take(ns * vslots * 10 * 8), o_vis = take(ns * vis_words * 8), o_sh = take(shadow_cap * 8 * 8);
+    const size_t o_counters = take(n_counters * 4);
+    if (ctx->wf_blob_bytes < off) {
+        if (ctx->wf_blob) (void)hipFree(ctx->wf_blob);
+        ctx->wf_blob = nullptr;
+        ctx->wf_blob_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->wf_blob, off));
+        ctx->wf_blob_bytes = off;
+    }
+    char* base = static_cast<char*>(ctx->wf_blob);
+    WfBuffers wb;
+    wb.ray = reinterpret_cast<double*>(base + o_ray); wb.thr = reinterpret_cast<double*>(base + o_thr);
+    wb.hit = reinterpret_cast<double*>(base + o_hit); wb.result = reinterpret_cast<double*>(base + o_res);
+    wb.hit_tri = reinterpret_cast<int32_t*>(base + o_tri); wb.ctr = reinterpret_cast<uint32_t*>(base + o_ctr);
+    wb.counts = reinterpret_cast<uint32_t*>(base + o_cnt);
+    wb.queue[0] = reinterpret_cast<uint32_t*>(base + o_q0); wb.queue[1] = reinterpret_cast<uint32_t*>(base + o_q1);
+    wb.conn_queue = reinterpret_cast<uint32_t*>(base + o_cq);
+    wb.vtx = reinterpret_cast<double*>(base + o_vtx); wb.vis = reinterpret_cast<unsigned long long*>(base + o_vis);
+    wb.shadow = reinterpret_cast<double*>(base + o_sh); wb.counters = reinterpret_cast<uint32_t*>(base + o_counters);
+    wb.ns = ns; wb.shadow_cap = shadow_cap; wb.vis_words = vis_words;
+
+    WfLaunchCfg cfg;
+    cfg.lds_scene = scene_fits_lds(scene->dev);
+    cfg.lds_bytes = cfg.lds_scene ? (size_t)scene->dev.n_nodes * sizeof(GpuNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri) : 0;
+    int per_cu = 1;
+    HIP_TRY(wf_persistent_blocks_per_cu(cfg.lds_scene, cfg.lds_bytes, &per_cu));
+    cfg.persistent_blocks = ctx->cu_count * per_cu;
+    cfg.stream_blocks = ctx->cu_count * 8;
+
+    const GpuCamera gcam = to_gpu_camera(*cam);
+    unsigned long long* stats = stats_mode ? ctx->stats : nullptr;
+    uint32_t* C = wb.counters;
+    auto eye_count = [&](int k) { return C + 8 + 2 * k; };
+    auto eye_cursor = [&](int k) { return C + 8 + 2 * k + 1; };
+    auto light_count = [&](int k) { return C + 8 + 2 * depth + 2 * k; };
+    auto light_cursor = [&](int k) { return C + 8 + 2 * depth + 2 * k + 1; };
+    auto shadow_count = [&](int a) { return C + 8 + 4 * depth + 2 * a; };
+    auto shadow_cursor = [&](int a) { return C + 8 + 4 * depth + 2 * a + 1; };
+    uint32_t* conn_count = C;
+
+    auto queue_empty = [&](const uint32_t* count_ptr, bool& empty) -> int {
+        uint32_t v = 0;
+        HIP_TRY(hipMemcpyAsync(&v, count_ptr, sizeof v, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        empty = (v == 0);
+        return BDPT_OK;
+    };
+
+    for (int64_t first = 0; first < n_owned; first += pixels_per_batch) {
+        WfBatch b;
+        b.seed = seed;
+        b.rows = ctx->rows;
+        b.row_w = x1 - x0; b.x0 = x0;
+        b.first_pixel = first;
+        b.n_pixels = (int32_t)((n_owned - first < pixels_per_batch) ? (n_owned - first) : pixels_per_batch);
+        b.pixels_stride = b.n_pixels;             // every slot below n_pixels * spp is a real sample
+        b.n_owned = n_owned;
+        const uint32_t n_slots = (uint32_t)((int64_t)b.n_pixels * spp);
+
+        HIP_TRY(hipMemsetAsync(C, 0, n_counters * 4, stream));
+        HIP_TRY(wf_gen_eye(scene->dev, gcam, wb, b, cfg, stream));
+        // eye subpath: camera.h:303 -> trace_path(r, depth, ...)
+        int cur = 0;
+        for (int k = 0; k < depth; k++) {
+            const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
+            const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
+            HIP_TRY(wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, stream));
+            const int nxt = (k == 0) ? 0 : (cur ^ 1);
+            HIP_TRY(wf_shade(scene->dev, gcam, wb, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, cfg,
+                             stats, stream));
+            cur = nxt;
+            if (k >= 3 && (k & 3) == 3 && k < depth - 1) {
+                bool empty = false;
+                int rc = queue_empty(eye_count(k), empty);
+                if (rc != BDPT_OK) return rc;
+                if (empty) break;
+            }
+        }
+        // light subpath: camera.h:313 -> build_light_path -> trace_path(light_ray, depth - 1, ...)
+        if (depth > 0) {
+            HIP_TRY(wf_gen_light(scene->dev, gcam, wb, b, wb.queue[0], light_count(0), cfg, stats, stream));
+            cur = 0;
+            for (int k = 0; k < depth - 1; k++) {
+                HIP_TRY(wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, stream));
+                HIP_TRY(wf_shade(scene->dev, gcam, wb, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
+                                 light_count(k + 1), k == depth - 2, cfg, stats, stream));
+                cur ^= 1;
+                if (k >= 3 && (k & 3) == 3 && k < depth - 2) {
+                    bool empty = false;
+                    int rc = queue_empty(light_count(k + 1), empty);
+                    if (rc != BDPT_OK) return rc;
+                    if (empty) break;
+                }
+            }
+        }
+        // connections: camera.h:316-320
+        HIP_TRY(wf_conn_prepare(gcam, wb, b, conn_count, cfg, stats, stream));
+        bool no_connections = false;
+        if (depth > 0) {
+            int rc = queue_empty(conn_count, no_connections);
+            if (rc != BDPT_OK) return rc;
+        }
+        for (int a = 0; a < depth && !no_connections; a++) {
+            HIP_TRY(wf_conn_gen(scene->dev, gcam, wb, a, conn_count, shadow_count(a), cfg, stats, stream));
+            HIP_TRY(wf_occlude(scene->dev, wb, shadow_count(a), shadow_cursor(a), cfg, stats, stream));
+            HIP_TRY(wf_conn_accum(scene->dev, gcam, wb, a, conn_count, cfg, stream));
+        }
+        HIP_TRY(wf_resolve(gcam, wb, b, d_fb, cfg, stream));
+    }
+    return BDPT_OK;
+}
+
 int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, const bdpt_render_params* p,
                 double* d_fb, hipStream_t stream) {
     if (!ctx || !scene || !cam || !p || !d_fb) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
@@ -147,39 +324,17 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     if (rc != BDPT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->rows, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));      // `rows` is a stack-lifetime host buffer
-    HIP_TRY(hipMemsetAsync(ctx->unit_counter, 0, sizeof(uint32_t), stream));
 
-    const int spp = cam->sqrt_spp * cam->sqrt_spp;
-    const int ppg = spp >= kBlock ? 1 : kBlock / spp;
     const int64_t n_owned = (int64_t)rows.size() * (x1 - x0);
-    const int64_t n_units = (n_owned + ppg - 1) / ppg;
-    if (n_units > 0x7FFFFFFF) return fail(BDPT_ERR_INVALID_ARGUMENT, "too many work units in one call");
-
-    // persistent grid: enough workgroups to fill the chip, never more than there is work
-    int per_cu = 1;
-    HIP_TRY(render_blocks_per_cu(scene->dev, stats_mode, &per_cu));
-    int64_t grid = (int64_t)ctx->cu_count * per_cu;
-    if (grid > n_units) grid = n_units;
-    const size_t ws_stride = (size_t)grid * kBlock;
-    const size_t slots = 2 * (size_t)(cam->max_depth > 0 ? cam->max_depth : 1);
-    rc = ensure_vertex_ws(ctx, align256(ws_stride * slots * 10 * sizeof(double)));
-    if (rc != BDPT_OK) return rc;
-
-    RenderLaunch rl;
-    rl.seed = p->seed;
-    rl.rows = ctx->rows;
-    rl.n_rows = (int32_t)rows.size();
-    rl.x0 = x0; rl.x1 = x1;
-    rl.pixels_per_group = ppg;
-    rl.n_units = (int32_t)n_units;
-    rl.unit_counter = ctx->unit_counter;
-    rl.fb = d_fb;
-    rl.vertex_ws = ctx->vertex_ws;
-    rl.stats = want_stats ? ctx->stats : nullptr;
-    rl.ws_stride = ws_stride;
     ctx->timing_valid = false;
     if (want_time) HIP_TRY(hipEventRecord(ctx->ev_start, stream));
-    HIP_TRY(launch_render(scene->dev, to_gpu_camera(*cam), rl, (int)grid, stats_mode, stream));
+    // Reference-equivalent counters need the reference's traversal of every shadow ray: that is the
+    // single-kernel path.  Everything else runs the wavefront pipeline unless the caller asks otherwise.
+    if (stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL))
+        rc = render_megakernel(ctx, scene, cam, p->seed, (int32_t)rows.size(), x0, x1, n_owned, d_fb, stats_mode, stream);
+    else
+        rc = render_wavefront(ctx, scene, cam, p->seed, x0, x1, n_owned, d_fb, stats_mode, stream);
+    if (rc != BDPT_OK) return rc;
     if (want_time) { HIP_TRY(hipEventRecord(ctx->ev_stop, stream)); ctx->timing_valid = true; }
     ctx->stats_valid = want_stats;
     return BDPT_OK;
@@ -224,6 +379,7 @@ int bdpt_context_destroy(bdpt_context* ctx) {
     if (ctx->rows) (void)hipFree(ctx->rows);
     if (ctx->unit_counter) (void)hipFree(ctx->unit_counter);
     if (ctx->stats) (void)hipFree(ctx->stats);
+    if (ctx->wf_blob) (void)hipFree(ctx->wf_blob);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;

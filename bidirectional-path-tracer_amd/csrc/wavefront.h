@@ -1,0 +1,78 @@
+// Wavefront (streaming) formulation of the radiance-estimation path: per-sample state lives in
+// HBM as structure-of-arrays, every subpath stage is its own kernel over a compacted queue of
+// live samples, and ray traversal runs in persistent waves that refill finished lanes.
+#ifndef BDPT_WAVEFRONT_H
+#define BDPT_WAVEFRONT_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bdpt_types.h"
+
+namespace bdpt {
+
+// Per-batch state, one entry per sample slot (capacity `ns`); slot = s * pixels_in_batch + p, so
+// neighbouring lanes hold the same sample index of neighbouring pixels.
+struct WfBuffers {
+    double* ray;          // [6][ns]  origin, direction of the ray to trace next
+    double* thr;          // [3][ns]  path throughput
+    double* hit;          // [3][ns]  t, u, v of the last closest hit
+    int32_t* hit_tri;     // [ns]     triangle id or -1
+    uint32_t* ctr;        // [ns]     random numbers drawn so far by the sample
+    double* result;       // [3][ns]  radiance of the sample
+    uint32_t* counts;     // [ns]     n_eye | n_light << 12 | flags << 24
+    double* vtx;          // [2*depth][10][ns]  stored (non-delta) path vertices: eye 0.., light depth..
+    unsigned long long* vis;   // [vis_words][ns]  visibility bits of the pairs (a, b = 0..) of the current eye vertex a
+    uint32_t* queue[2];   // [ns]     live-sample queues (ping-pong)
+    uint32_t* conn_queue; // [ns]     samples that have both eye and light vertices
+    double* shadow;       // [8][shadow_cap]  shadow rays: origin, direction, max_t, tag (slot, b)
+    uint32_t* counters;   // queue sizes and work-distribution cursors, zeroed once per batch
+    uint64_t ns;
+    uint64_t shadow_cap;
+    uint32_t vis_words;
+};
+
+constexpr uint32_t kCntEyeHit = 1u << 24, kCntLightHit = 1u << 25, kCntLightValid = 1u << 26;
+
+struct WfBatch {
+    uint64_t seed;
+    const int32_t* rows;      // owned rows
+    int32_t row_w, x0;        // owned column range
+    int64_t first_pixel;      // ordinal (in owned-pixel order) of the batch's first pixel
+    int32_t n_pixels;         // pixels in this batch
+    int32_t pixels_stride;    // slot = s * pixels_stride + p
+    int64_t n_owned;
+};
+
+struct WfLaunchCfg {
+    int persistent_blocks;    // grid of the persistent traversal kernels
+    int stream_blocks;        // grid of the grid-stride kernels
+    bool lds_scene;
+    size_t lds_bytes;
+};
+
+// counts of the work done, accumulated by the kernels when `stats` is non-null (bdpt_stats order)
+hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const WfLaunchCfg& cfg,
+                      hipStream_t st);
+hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
+                     uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
+hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
+                    const uint32_t* queue_in, const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
+                    uint32_t* count_out, bool last_bounce, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
+hipError_t wf_gen_light(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* queue_out,
+                        uint32_t* count_out, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
+hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* conn_count,
+                           const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
+hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
+                       uint32_t* shadow_count, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
+hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t* cursor,
+                      const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
+hipError_t wf_conn_accum(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
+                         const WfLaunchCfg& cfg, hipStream_t st);
+hipError_t wf_resolve(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, double* fb, const WfLaunchCfg& cfg,
+                      hipStream_t st);
+
+hipError_t wf_persistent_blocks_per_cu(bool lds_scene, size_t lds_bytes, int* out);
+
+}  // namespace bdpt
+#endif

@@ -1,0 +1,581 @@
+// Wavefront kernels (gfx950, wave64).  See wavefront.h for the data layout.
+//
+// Stage kernels are grid-stride over a queue of sample slots; the two traversal kernels are
+// persistent: a wave draws ray indices in chunks from a global cursor and hands them to lanes as
+// they finish, so lanes whose ray ended early do not idle until the slowest ray of the wave is done.
+#include <hip/hip_runtime.h>
+
+#include "device_core.h"
+#include "wavefront.h"
+
+namespace bdpt {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kRefillThreshold = 16;   // refill when at least this many lanes of a wave are idle
+constexpr uint32_t kChunk = 256;       // ray indices a wave takes from the global cursor at a time
+
+BDPT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
+BDPT_DEV uint32_t rank_in_mask(unsigned long long mask) {
+    return __builtin_popcountll(mask & ((1ull << lane_id()) - 1ull));
+}
+
+// append `flag`-ged lanes' values to a queue: one atomic per wave
+BDPT_DEV void wave_append(bool flag, uint32_t value, uint32_t* queue, uint32_t* count) {
+    unsigned long long m = __ballot(flag);
+    if (m == 0) return;
+    uint32_t base = 0;
+    const int leader = __builtin_ctzll(m);
+    if ((int)lane_id() == leader) base = atomicAdd(count, (uint32_t)__builtin_popcountll(m));
+    base = __shfl(base, leader, 64);
+    if (flag) queue[base + rank_in_mask(m)] = value;
+}
+
+BDPT_DEV void flush_wave_counter(unsigned long long* dst, unsigned long long x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if (lane_id() == 0 && x) atomicAdd(dst, x);
+}
+
+// pixel (i, j) and stratum (s_i, s_j) of a slot; false for slots past the end of the batch / image
+BDPT_DEV bool slot_to_sample(const GpuCamera& cam, const WfBatch& b, uint32_t slot, int& i, int& j, int& s) {
+    const int p = (int)(slot % (uint32_t)b.pixels_stride);
+    s = (int)(slot / (uint32_t)b.pixels_stride);
+    const long long q = b.first_pixel + p;
+    if (p >= b.n_pixels || q >= b.n_owned) return false;
+    j = b.rows[q / b.row_w];
+    i = b.x0 + (int)(q % b.row_w);
+    return true;
+}
+
+BDPT_DEV Rng slot_rng(const GpuCamera& cam, const WfBatch& b, uint32_t slot, uint32_t counter) {
+    int i, j, s;
+    slot_to_sample(cam, b, slot, i, j, s);
+    Rng rng;
+    rng.key = stream_key(b.seed, (uint64_t)j * (uint64_t)cam.width + (uint64_t)i, (uint64_t)s);
+    rng.counter = counter;
+    return rng;
+}
+
+BDPT_DEV VertexStore slot_store(const WfBuffers& wb, uint32_t slot) {
+    VertexStore st;
+    st.ws = wb.vtx;
+    st.stride = wb.ns;
+    st.g = slot;
+    return st;
+}
+
+BDPT_DEV void stage_scene(const SceneDev& sc, GpuNode* l_nodes, GpuTri* l_tris) {
+    const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
+    uint4* dst = reinterpret_cast<uint4*>(l_nodes);
+    const uint32_t n16 = sc.n_nodes * (sizeof(GpuNode) / 16);
+    for (uint32_t k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
+    src = reinterpret_cast<const uint4*>(sc.tris);
+    dst = reinterpret_cast<uint4*>(l_tris);
+    const uint32_t t16 = sc.n_tris * (sizeof(GpuTri) / 16);
+    for (uint32_t k = threadIdx.x; k < t16; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ camera rays
+__global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb, WfBatch b) {
+    const uint32_t spp = (uint32_t)(cam.sqrt_spp * cam.sqrt_spp);
+    const uint64_t n = (uint64_t)b.pixels_stride * spp;
+    for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * kBlock) {
+        int i, j, s;
+        wb.hit_tri[slot] = -1;
+        wb.counts[slot] = 0;
+        wb.result[slot] = 0.0; wb.result[wb.ns + slot] = 0.0; wb.result[2 * wb.ns + slot] = 0.0;
+        if (!slot_to_sample(cam, b, (uint32_t)slot, i, j, s)) {
+            wb.ctr[slot] = 0;
+            // inactive slots still get a harmless ray (they are traced in the first bounce like all others)
+            wb.ray[slot] = 0; wb.ray[wb.ns + slot] = 0; wb.ray[2 * wb.ns + slot] = 0;
+            wb.ray[3 * wb.ns + slot] = 0; wb.ray[4 * wb.ns + slot] = 0; wb.ray[5 * wb.ns + slot] = 0;
+            continue;
+        }
+        Rng rng;
+        rng.key = stream_key(b.seed, (uint64_t)j * (uint64_t)cam.width + (uint64_t)i, (uint64_t)s);
+        rng.counter = 0;
+        const int s_j = s / cam.sqrt_spp, s_i = s - s_j * cam.sqrt_spp;
+        V3 o, d;
+        camera_ray(cam, i, j, s_i, s_j, rng, o, d);
+        wb.ray[slot] = o.x; wb.ray[wb.ns + slot] = o.y; wb.ray[2 * wb.ns + slot] = o.z;
+        wb.ray[3 * wb.ns + slot] = d.x; wb.ray[4 * wb.ns + slot] = d.y; wb.ray[5 * wb.ns + slot] = d.z;
+        wb.thr[slot] = 1.0; wb.thr[wb.ns + slot] = 1.0; wb.thr[2 * wb.ns + slot] = 1.0;
+        wb.ctr[slot] = rng.counter;
+    }
+}
+
+// ------------------------------------------------------------------ persistent traversal
+// One loop iteration = one node visit of every lane that holds a ray.  SHADOW: rays come from the
+// shadow queue, the walk stops at the first hit and a clear ray sets its pair's visibility bit.
+template <bool SHADOW, bool STATS, class Mem>
+BDPT_DEV void traverse_queue(const Mem& mem, const WfBuffers& wb, const uint32_t* queue, uint32_t count, uint32_t* cursor,
+                             unsigned long long* stats) {
+    bool has = false;
+    uint32_t slot = 0, node = 0;
+    unsigned long long tag = 0;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
+    double ix = 0, iy = 0, iz = 0, closest = 0, tmax0 = 0;
+    HitLite h;
+    h.t = 0; h.u = 0; h.v = 0; h.tri = -1;
+    uint32_t pool_next = 0, pool_end = 0;     // wave-uniform
+    bool exhausted = (count == 0);
+    uint32_t n_nodes = 0, n_box_hits = 0, n_tri = 0, n_tri_hits = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        const int n_idle = __builtin_popcountll(idle);
+        if (!exhausted && (n_idle >= kRefillThreshold)) {
+            if (pool_next == pool_end) {
+                uint32_t base = 0;
+                if (lane_id() == 0) base = atomicAdd(cursor, kChunk);
+                base = __shfl(base, 0, 64);
+                if (base >= count) { exhausted = true; pool_next = pool_end = 0; }
+                else { pool_next = base; pool_end = (base + kChunk < count) ? base + kChunk : count; }
+            }
+            const uint32_t avail = pool_end - pool_next;
+            const uint32_t give = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
+            if (!has) {
+                const uint32_t r = rank_in_mask(idle);
+                if (r < give) {
+                    const uint32_t k = pool_next + r;
+                    if (SHADOW) {
+                        const uint64_t cap = wb.shadow_cap;
+                        o = mk(wb.shadow[k], wb.shadow[cap + k], wb.shadow[2 * cap + k]);
+                        d = mk(wb.shadow[3 * cap + k], wb.shadow[4 * cap + k], wb.shadow[5 * cap + k]);
+                        tmax0 = wb.shadow[6 * cap + k];
+                        tag = (unsigned long long)__double_as_longlong(wb.shadow[7 * cap + k]);
+                    } else {
+                        slot = queue ? queue[k] : k;
+                        const uint64_t ns = wb.ns;
+                        o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
+                        d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
+                        tmax0 = kInf;
+                    }
+                    ix = 1.0 / d.x; iy = 1.0 / d.y; iz = 1.0 / d.z;       // aabb.h:48, once per ray
+                    closest = tmax0;
+                    node = 0;
+                    h.tri = -1;
+                    has = true;
+                }
+            }
+            pool_next += give;
+        }
+        if (__ballot(has) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        if (has) {
+            const GpuNode nd = mem.node(node);
+            if (STATS) n_nodes++;
+            double lo = 0.001, hi = closest;
+            {
+                double t0 = (nd.lo[0] - o.x) * ix, t1 = (nd.hi[0] - o.x) * ix;
+                double nr = (t0 < t1) ? t0 : t1, fr = (t0 < t1) ? t1 : t0;
+                lo = (nr > lo) ? nr : lo; hi = (fr < hi) ? fr : hi;
+            }
+            {
+                double t0 = (nd.lo[1] - o.y) * iy, t1 = (nd.hi[1] - o.y) * iy;
+                double nr = (t0 < t1) ? t0 : t1, fr = (t0 < t1) ? t1 : t0;
+                lo = (nr > lo) ? nr : lo; hi = (fr < hi) ? fr : hi;
+            }
+            {
+                double t0 = (nd.lo[2] - o.z) * iz, t1 = (nd.hi[2] - o.z) * iz;
+                double nr = (t0 < t1) ? t0 : t1, fr = (t0 < t1) ? t1 : t0;
+                lo = (nr > lo) ? nr : lo; hi = (fr < hi) ? fr : hi;
+            }
+            bool done = false;
+            if (hi <= lo) {
+                node = nd.skip;
+            } else {
+                if (STATS) n_box_hits++;
+                if (nd.tri0 >= 0) {
+                    double t, u, v;
+                    {
+                        const GpuTri tr = mem.tri(nd.tri0);
+                        const bool hit = tri_test(tr, o, d, 0.001, closest, t, u, v);
+                        if (STATS) { n_tri++; if (hit) n_tri_hits++; }
+                        if (hit) { closest = t; h.t = t; h.u = u; h.v = v; h.tri = nd.tri0; if (SHADOW) done = true; }
+                    }
+                    if (nd.tri1 != nd.tri0 && !done) {
+                        const GpuTri tr = mem.tri(nd.tri1);
+                        const bool hit = tri_test(tr, o, d, 0.001, closest, t, u, v);
+                        if (STATS) { n_tri++; if (hit) n_tri_hits++; }
+                        if (hit) { closest = t; h.t = t; h.u = u; h.v = v; h.tri = nd.tri1; if (SHADOW) done = true; }
+                    }
+                }
+                node = nd.next;
+            }
+            if (node == kEndOfTree) done = true;
+            if (done) {
+                if (SHADOW) {
+                    if (h.tri < 0) {       // nothing in the way: the pair is visible
+                        const uint32_t s = (uint32_t)(tag >> 16);
+                        const uint32_t bidx = (uint32_t)(tag & 0xFFFFu);
+                        atomicOr(&wb.vis[(uint64_t)(bidx >> 6) * wb.ns + s], 1ull << (bidx & 63u));
+                    }
+                } else {
+                    const uint64_t ns = wb.ns;
+                    wb.hit_tri[slot] = h.tri;
+                    if (h.tri >= 0) { wb.hit[slot] = h.t; wb.hit[ns + slot] = h.u; wb.hit[2 * ns + slot] = h.v; }
+                }
+                has = false;
+            }
+        }
+    }
+    if (STATS) {
+        flush_wave_counter(&stats[1], n_nodes);
+        flush_wave_counter(&stats[2], n_box_hits);
+        flush_wave_counter(&stats[3], n_nodes);
+        flush_wave_counter(&stats[4], n_tri);
+        flush_wave_counter(&stats[5], n_tri_hits);
+    }
+}
+
+template <bool SHADOW, bool STATS, bool LDS_SCENE>
+__global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
+                                                     const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
+                                                     unsigned long long* stats) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t count = count_ptr ? *count_ptr : count_imm;
+    if (LDS_SCENE) {
+        GpuNode* l_nodes = reinterpret_cast<GpuNode*>(smem);
+        GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_nodes);
+        stage_scene(sc, l_nodes, l_tris);
+        LdsScene mem{l_nodes, l_tris};
+        traverse_queue<SHADOW, STATS>(mem, wb, queue, count, cursor, stats);
+    } else {
+        GlobalScene mem{sc.nodes, sc.tris};
+        traverse_queue<SHADOW, STATS>(mem, wb, queue, count, cursor, stats);
+    }
+    if (STATS && !SHADOW && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)count);
+    if (STATS && SHADOW && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[6], (unsigned long long)count);
+}
+
+// ------------------------------------------------------------------ shading of one bounce
+template <bool EYE, bool STATS>
+__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
+                                                  const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
+                                                  uint32_t* count_out, int last_bounce, unsigned long long* stats) {
+    const uint32_t count = count_in_ptr ? *count_in_ptr : count_in_imm;
+    const uint64_t ns = wb.ns;
+    const int depth = cam.max_depth;
+    uint32_t n_stored = 0;
+    // whole waves iterate together so that the ballot-based append sees every lane
+    const uint32_t rounded = (count + 63u) & ~63u;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < rounded; k += gridDim.x * kBlock) {
+        bool cont = false;
+        uint32_t slot = 0;
+        if (k < count) {
+            slot = queue_in ? queue_in[k] : k;
+            int pi, pj, ps;
+            const bool active = slot_to_sample(cam, b, slot, pi, pj, ps);
+            const int32_t tri = wb.hit_tri[slot];
+            if (active) {
+                V3 T = mk(wb.thr[slot], wb.thr[ns + slot], wb.thr[2 * ns + slot]);
+                if (tri < 0) {
+                    if (EYE) {   // camera.h:337-338: background_contrib (0) += throughput * background
+                        V3 bg = add(mk(0, 0, 0), mulv(T, ld3(cam.background)));
+                        wb.result[slot] = bg.x; wb.result[ns + slot] = bg.y; wb.result[2 * ns + slot] = bg.z;
+                    }
+                } else {
+                    V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
+                    V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
+                    HitLite h;
+                    h.tri = tri; h.t = wb.hit[slot]; h.u = wb.hit[ns + slot]; h.v = wb.hit[2 * ns + slot];
+                    Rng rng = slot_rng(cam, b, slot, wb.ctr[slot]);
+                    Bounce bo;
+                    shade_bounce<EYE>(sc, o, d, h, T, rng, bo);
+                    uint32_t cnt = wb.counts[slot] | (EYE ? kCntEyeHit : kCntLightHit);
+                    if (bo.keep) {
+                        const uint32_t ne = cnt & 0xFFFu, nl = (cnt >> 12) & 0xFFFu;
+                        slot_store(wb, slot).put(EYE ? (int)ne : depth + (int)nl, bo.vx);
+                        cnt += EYE ? 1u : (1u << 12);
+                        if (STATS) n_stored++;
+                    }
+                    wb.counts[slot] = cnt;
+                    if (EYE && bo.emitted) {   // result = background_contrib (0) + throughput * emission
+                        V3 e = add(mk(0, 0, 0), bo.emitted_term);
+                        wb.result[slot] = e.x; wb.result[ns + slot] = e.y; wb.result[2 * ns + slot] = e.z;
+                    }
+                    wb.ctr[slot] = rng.counter;
+                    if (bo.cont && !last_bounce) {
+                        cont = true;
+                        wb.ray[slot] = bo.o.x; wb.ray[ns + slot] = bo.o.y; wb.ray[2 * ns + slot] = bo.o.z;
+                        wb.ray[3 * ns + slot] = bo.d.x; wb.ray[4 * ns + slot] = bo.d.y; wb.ray[5 * ns + slot] = bo.d.z;
+                        wb.thr[slot] = bo.T.x; wb.thr[ns + slot] = bo.T.y; wb.thr[2 * ns + slot] = bo.T.z;
+                    }
+                }
+            }
+        }
+        wave_append(cont, slot, queue_out, count_out);
+    }
+    if (STATS) flush_wave_counter(&stats[10], n_stored);
+}
+
+// ------------------------------------------------------------------ light subpath start
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_gen_light(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, uint32_t* queue_out,
+                                                      uint32_t* count_out, unsigned long long* stats) {
+    const uint32_t spp = (uint32_t)(cam.sqrt_spp * cam.sqrt_spp);
+    const uint32_t n = (uint32_t)b.pixels_stride * spp;
+    const uint64_t ns = wb.ns;
+    const int depth = cam.max_depth;
+    const uint32_t rounded = (n + 63u) & ~63u;
+    uint32_t n_stored = 0;
+    for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < rounded; slot += gridDim.x * kBlock) {
+        bool cont = false;
+        int pi, pj, ps;
+        if (slot < n && slot_to_sample(cam, b, slot, pi, pj, ps)) {
+            Rng rng = slot_rng(cam, b, slot, wb.ctr[slot]);
+            Emitter em;
+            sample_emitter(sc, depth, rng, em);
+            wb.ctr[slot] = rng.counter;
+            if (em.valid) {
+                slot_store(wb, slot).put(depth, em.ev);
+                if (STATS) n_stored++;
+                wb.counts[slot] = wb.counts[slot] | kCntLightValid | kCntLightHit | (1u << 12);
+                if (em.has_ray && depth - 1 > 0) {
+                    cont = true;
+                    wb.ray[slot] = em.o.x; wb.ray[ns + slot] = em.o.y; wb.ray[2 * ns + slot] = em.o.z;
+                    wb.ray[3 * ns + slot] = em.d.x; wb.ray[4 * ns + slot] = em.d.y; wb.ray[5 * ns + slot] = em.d.z;
+                    wb.thr[slot] = em.T.x; wb.thr[ns + slot] = em.T.y; wb.thr[2 * ns + slot] = em.T.z;
+                }
+            }
+        }
+        wave_append(cont, slot, queue_out, count_out);
+    }
+    if (STATS) flush_wave_counter(&stats[10], n_stored);
+}
+
+// ------------------------------------------------------------------ connections
+// samples that have a light path and at least one stored vertex on both sides
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_conn_prepare(GpuCamera cam, WfBuffers wb, WfBatch b, uint32_t* conn_count,
+                                                         unsigned long long* stats) {
+    const uint32_t spp = (uint32_t)(cam.sqrt_spp * cam.sqrt_spp);
+    const uint32_t n = (uint32_t)b.pixels_stride * spp;
+    const uint64_t ns = wb.ns;
+    const uint32_t rounded = (n + 63u) & ~63u;
+    unsigned long long draws = 0, samples = 0;
+    for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < rounded; slot += gridDim.x * kBlock) {
+        bool want = false;
+        int pi, pj, ps;
+        if (slot < n && slot_to_sample(cam, b, slot, pi, pj, ps)) {
+            const uint32_t cnt = wb.counts[slot];
+            if (STATS) { draws += wb.ctr[slot]; samples++; }
+            if (cnt & kCntLightValid) {
+                // camera.h:316-320 adds a colour (possibly zero) for every vertex pair: x + (+0) only
+                // changes a -0 accumulator, which this one add normalises
+                if ((cnt & kCntEyeHit) && (cnt & kCntLightHit)) {
+                    wb.result[slot] = wb.result[slot] + 0.0;
+                    wb.result[ns + slot] = wb.result[ns + slot] + 0.0;
+                    wb.result[2 * ns + slot] = wb.result[2 * ns + slot] + 0.0;
+                }
+                want = (cnt & 0xFFFu) > 0 && ((cnt >> 12) & 0xFFFu) > 0;
+            }
+        }
+        wave_append(want, slot, wb.conn_queue, conn_count);
+    }
+    if (STATS) { flush_wave_counter(&stats[8], draws); flush_wave_counter(&stats[9], samples); }
+}
+
+// shadow rays of eye vertex `a` against every light vertex of the sample
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_conn_gen(SceneDev sc, GpuCamera cam, WfBuffers wb, int a, const uint32_t* conn_count,
+                                                     uint32_t* shadow_count, unsigned long long* stats) {
+    const uint32_t count = *conn_count;
+    const int depth = cam.max_depth;
+    const uint32_t rounded = (count + 63u) & ~63u;
+    uint32_t n_pairs = 0;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < rounded; k += gridDim.x * kBlock) {
+        uint32_t slot = 0;
+        int n_light = 0;
+        Vertex cv;
+        bool cam_ok = false;
+        if (k < count) {
+            slot = wb.conn_queue[k];
+            const uint32_t cnt = wb.counts[slot];
+            if ((uint32_t)a < (cnt & 0xFFFu)) {
+                n_light = (int)((cnt >> 12) & 0xFFFu);
+                for (uint32_t w = 0; w < wb.vis_words; w++) wb.vis[(uint64_t)w * wb.ns + slot] = 0ull;
+                cv = slot_store(wb, slot).get(a);
+                if (STATS) n_pairs += (uint32_t)n_light;
+                // an eye vertex on an emitter has a zero BSDF (material.h:35-37): every pair it forms
+                // contributes zero whatever the visibility, so no ray is spent on it
+                cam_ok = !(cv.info & kVtxIsLight);
+            }
+        }
+        const int max_light = cam_ok ? n_light : 0;
+        int wave_max = max_light;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { int o2 = __shfl_xor(wave_max, off, 64); wave_max = o2 > wave_max ? o2 : wave_max; }
+        for (int bi = 0; bi < wave_max; bi++) {
+            bool emit = false;
+            PairGeom g;
+            if (bi < max_light) {
+                const Vertex lv = slot_store(wb, slot).get(depth + bi);
+                V3 f_cam, f_light;
+                emit = pair_geometry(cv, lv, g) && pair_factors(sc, cv, lv, f_cam, f_light);
+            }
+            const unsigned long long m = __ballot(emit);
+            if (m == 0) continue;
+            uint32_t base = 0;
+            const int leader = __builtin_ctzll(m);
+            if ((int)lane_id() == leader) base = atomicAdd(shadow_count, (uint32_t)__builtin_popcountll(m));
+            base = __shfl(base, leader, 64);
+            if (emit) {
+                const uint64_t e = base + rank_in_mask(m);
+                const uint64_t cap = wb.shadow_cap;
+                wb.shadow[e] = g.origin.x; wb.shadow[cap + e] = g.origin.y; wb.shadow[2 * cap + e] = g.origin.z;
+                wb.shadow[3 * cap + e] = g.dir_unit.x; wb.shadow[4 * cap + e] = g.dir_unit.y; wb.shadow[5 * cap + e] = g.dir_unit.z;
+                wb.shadow[6 * cap + e] = g.max_t;
+                wb.shadow[7 * cap + e] = __longlong_as_double((long long)(((unsigned long long)slot << 16) | (unsigned)bi));
+            }
+        }
+    }
+    if (STATS) flush_wave_counter(&stats[7], n_pairs);
+}
+
+// adds the contributions of eye vertex `a` in light-vertex order (camera.h:316-320, 471-474)
+__global__ __launch_bounds__(kBlock) void k_conn_accum(SceneDev sc, GpuCamera cam, WfBuffers wb, int a, const uint32_t* conn_count) {
+    const uint32_t count = *conn_count;
+    const int depth = cam.max_depth;
+    const uint64_t ns = wb.ns;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
+        const uint32_t slot = wb.conn_queue[k];
+        const uint32_t cnt = wb.counts[slot];
+        if ((uint32_t)a >= (cnt & 0xFFFu)) continue;
+        const int n_light = (int)((cnt >> 12) & 0xFFFu);
+        const Vertex cv = slot_store(wb, slot).get(a);
+        V3 result = mk(wb.result[slot], wb.result[ns + slot], wb.result[2 * ns + slot]);
+        bool changed = false;
+        for (int bi = 0; bi < n_light; bi++) {
+            const unsigned long long word = wb.vis[(uint64_t)(bi >> 6) * ns + slot];
+            if (!((word >> (bi & 63)) & 1ull)) continue;
+            const Vertex lv = slot_store(wb, slot).get(depth + bi);
+            PairGeom g;
+            V3 f_cam, f_light;
+            if (!pair_geometry(cv, lv, g) || !pair_factors(sc, cv, lv, f_cam, f_light)) continue;
+            result = add(result, pair_contribution(cv, lv, g, f_cam, f_light));
+            changed = true;
+        }
+        if (changed) { wb.result[slot] = result.x; wb.result[ns + slot] = result.y; wb.result[2 * ns + slot] = result.z; }
+    }
+}
+
+// per-pixel sum over the samples in the reference's order (s_j outer, s_i inner, camera.h:118-123)
+__global__ __launch_bounds__(kBlock) void k_resolve(GpuCamera cam, WfBuffers wb, WfBatch b, double* fb) {
+    const int spp = cam.sqrt_spp * cam.sqrt_spp;
+    const uint32_t n = (uint32_t)b.n_pixels * 3u;
+    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n; t += gridDim.x * kBlock) {
+        const int ch = (int)(t / (uint32_t)b.n_pixels);
+        const int p = (int)(t - (uint32_t)ch * (uint32_t)b.n_pixels);
+        const long long q = b.first_pixel + p;
+        if (q >= b.n_owned) continue;
+        const double* src = wb.result + (uint64_t)ch * wb.ns + p;
+        double acc = 0.0;
+        for (int s = 0; s < spp; s++) acc = acc + src[(uint64_t)s * b.pixels_stride];
+        const int j = b.rows[q / b.row_w];
+        const int i = b.x0 + (int)(q % b.row_w);
+        fb[((size_t)j * cam.width + i) * 3 + ch] = acc;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ launchers
+hipError_t wf_persistent_blocks_per_cu(bool lds_scene, size_t lds_bytes, int* out) {
+    int n = 0;
+    hipError_t e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<false, false, true>, kBlock, lds_bytes)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<false, false, false>, kBlock, 0);
+    *out = n < 1 ? 1 : n;
+    return e;
+}
+
+hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const WfLaunchCfg& cfg,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(k_gen_eye, dim3(cfg.stream_blocks), dim3(kBlock), 0, st, cam, wb, b);
+    return hipGetLastError();
+}
+
+template <bool SHADOW>
+static hipError_t launch_traverse(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
+                                  uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
+                                  hipStream_t st) {
+    dim3 grid(cfg.persistent_blocks), block(kBlock);
+    const size_t shm = cfg.lds_scene ? cfg.lds_bytes : 0;
+    if (stats) {
+        if (cfg.lds_scene) hipLaunchKernelGGL((k_traverse<SHADOW, true, true>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats);
+        else hipLaunchKernelGGL((k_traverse<SHADOW, true, false>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats);
+    } else {
+        if (cfg.lds_scene) hipLaunchKernelGGL((k_traverse<SHADOW, false, true>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats);
+        else hipLaunchKernelGGL((k_traverse<SHADOW, false, false>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats);
+    }
+    return hipGetLastError();
+}
+
+hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
+                     uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
+    return launch_traverse<false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+}
+
+hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t* cursor,
+                      const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
+    return launch_traverse<true>(sc, wb, nullptr, shadow_count, 0, cursor, cfg, stats, st);
+}
+
+hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
+                    const uint32_t* queue_in, const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
+                    uint32_t* count_out, bool last_bounce, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
+    dim3 grid(cfg.stream_blocks), block(kBlock);
+    const int last = last_bounce ? 1 : 0;
+    if (eye) {
+        if (stats) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, stats);
+        else hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, stats);
+    } else {
+        if (stats) hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, stats);
+        else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, stats);
+    }
+    return hipGetLastError();
+}
+
+hipError_t wf_gen_light(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* queue_out,
+                        uint32_t* count_out, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
+    dim3 grid(cfg.stream_blocks), block(kBlock);
+    if (stats) hipLaunchKernelGGL((k_gen_light<true>), grid, block, 0, st, sc, cam, wb, b, queue_out, count_out, stats);
+    else hipLaunchKernelGGL((k_gen_light<false>), grid, block, 0, st, sc, cam, wb, b, queue_out, count_out, stats);
+    return hipGetLastError();
+}
+
+hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* conn_count,
+                           const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
+    dim3 grid(cfg.stream_blocks), block(kBlock);
+    if (stats) hipLaunchKernelGGL((k_conn_prepare<true>), grid, block, 0, st, cam, wb, b, conn_count, stats);
+    else hipLaunchKernelGGL((k_conn_prepare<false>), grid, block, 0, st, cam, wb, b, conn_count, stats);
+    return hipGetLastError();
+}
+
+hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
+                       uint32_t* shadow_count, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
+    dim3 grid(cfg.stream_blocks), block(kBlock);
+    if (stats) hipLaunchKernelGGL((k_conn_gen<true>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
+    else hipLaunchKernelGGL((k_conn_gen<false>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
+    return hipGetLastError();
+}
+
+hipError_t wf_conn_accum(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
+                         const WfLaunchCfg& cfg, hipStream_t st) {
+    hipLaunchKernelGGL(k_conn_accum, dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
+    return hipGetLastError();
+}
+
+hipError_t wf_resolve(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, double* fb, const WfLaunchCfg& cfg,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(k_resolve, dim3(cfg.stream_blocks), dim3(kBlock), 0, st, cam, wb, b, fb);
+    return hipGetLastError();
+}
+
+}  // namespace bdpt

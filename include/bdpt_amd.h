@@ -100,6 +100,8 @@ typedef struct bdpt_render_params {
                                        equals what the CPU renderer prints (slower; for verification) */
 #define BDPT_RENDER_COUNT_WORK 2    /* accumulate bdpt_stats of the work the production path does (visibility queries
                                        stop at the first hit); ignored when BDPT_RENDER_COUNT_STATS is set */
+#define BDPT_RENDER_MEGAKERNEL 8    /* render with the single persistent kernel (one thread per sample) instead of the
+                                       wavefront pipeline; same framebuffer bit for bit (BDPT_RENDER_COUNT_STATS implies it) */
 #define BDPT_RENDER_TIME_KERNEL 4   /* bracket the render kernel with HIP events on its stream (bdpt_render_get_kernel_ms) */
 
 /* Work counters.  The first six have the meaning of the reference's BvhStats

@@ -135,8 +135,17 @@ def test_render_matches_reference_bit_for_bit(case):
     assert got == ref[:6], "BvhStats counters of the whole render"
     assert st.rng_draws == ref[7]
     assert st.samples == (y1 - y0) * (x1 - x0) * cam.sqrt_spp ** 2
-    # the production variant (no counters, any-hit shadow rays) gives the same image
-    assert_bit_equal(sc.render(cam, seed=int(g["render_seed"][0]), rect=(x0, y0, x1, y1)), fb, "no-stats kernel")
+    # the production paths (no counters, shadow rays stop at the first hit) give the same image:
+    # the wavefront pipeline (default) and the single persistent kernel
+    seed = int(g["render_seed"][0])
+    assert_bit_equal(sc.render(cam, seed=seed, rect=(x0, y0, x1, y1)), fb, "wavefront pipeline")
+    assert_bit_equal(sc.render(cam, seed=seed, rect=(x0, y0, x1, y1), megakernel=True), fb, "single kernel")
+    # work counters of the wavefront pipeline: same rays, draws, vertices and pairs as the reference path
+    fb2, sw = sc.render(cam, seed=seed, rect=(x0, y0, x1, y1), want_stats="work")
+    assert_bit_equal(fb2, fb, "wavefront pipeline with work counters")
+    assert (sw.rays_traced, sw.rng_draws, sw.samples, sw.path_vertices, sw.connection_pairs) == \
+           (st.rays_traced, st.rng_draws, st.samples, st.path_vertices, st.connection_pairs)
+    assert sw.shadow_rays <= st.shadow_rays and sw.aabb_tests <= st.aabb_tests
 
 
 def test_render_matches_oracle_on_other_seeds(case, oracle):
