@@ -231,7 +231,7 @@ def main():
                             megakernel=args.megakernel)
         st = scene.last_stats()
         frac = st.samples / float(W * H * spp_used)
-        alg = (B_RAY * (st.rays_traced + st.shadow_rays) + B_NODE * st.aabb_tests + B_TRI * st.triangle_tests +
+        alg = (B_RAY * (st.rays_traced + st.shadow_rays) + B_NODE * st.bvh_node_visits + B_TRI * st.triangle_tests +
                B_VERTEX * (st.path_vertices + 2 * st.connection_pairs) + B_PIXEL * (st.samples / spp_used)) / frac
         ms = sum(kernel_ms) / len(kernel_ms)
         achieved = alg / (ms * 1e-3) / 1e9
@@ -249,7 +249,7 @@ def main():
             "kernel": "render_kernel (single persistent kernel)" if args.megakernel else "wavefront pipeline (all kernels of one frame)",
             "kernel_ms": ms, "algorithmic_bytes_per_launch": alg,
             "per_sample": {"trace_rays": st.rays_traced / st.samples, "shadow_rays": st.shadow_rays / st.samples,
-                           "node_visits": st.aabb_tests / st.samples, "triangle_tests": st.triangle_tests / st.samples,
+                           "box_tests": st.aabb_tests / st.samples, "node_records_64B": st.bvh_node_visits / st.samples, "triangle_tests": st.triangle_tests / st.samples,
                            "connection_pairs": st.connection_pairs / st.samples, "rng_draws": st.rng_draws / st.samples},
             "rays_per_s": (st.rays_traced + st.shadow_rays) / frac / (ms * 1e-3),
         }

@@ -31,9 +31,38 @@ struct GpuTri {
     double e1[3];
     double e2[3];
     int32_t material;
-    int32_t pad;
+    int32_t pad;      // leaf-ordered copy: original triangle id
 };
 static_assert(sizeof(GpuTri) == 80, "GpuTri must stay 80 bytes");
+
+// The same tree in "wide" form for ORDERED traversal with a small per-lane stack: one 128-byte
+// record (a full cache line) per interior bvh_node holding the boxes of BOTH children, so one
+// fetch decides which child is nearer and whether the farther one is needed at all.  The boxes
+// are the reference's FP64 node boxes, bit for bit, so a box test here is the test the reference
+// makes when it visits that child (src/acceleration/bvh.h:52).  Child reference: >= 0 index of an
+// interior record; < 0 a leaf, ~ref = (first << 2) | (count - 1): `count` triangles starting at
+// position `first` of the triangle table sorted in the reference's left-to-right leaf order.
+struct GpuWideNode {
+    double lo0[3], hi0[3];
+    double lo1[3], hi1[3];
+    int32_t child0, child1;
+    int32_t pad[6];
+};
+static_assert(sizeof(GpuWideNode) == 128, "GpuWideNode must stay 128 bytes");
+
+// Closest-hit queries do not depend on the shape of the tree (the answer is the nearest accepted
+// triangle, ties resolved by the reference's leaf order), so they use a separate hierarchy built
+// with a binned surface-area heuristic: 64-byte records, both child boxes in FP32 rounded OUTWARD
+// (a box here always contains the padded FP64 box of everything below it, so culling is
+// conservative), leaves of up to four triangles, same child reference encoding as GpuWideNode.
+// The triangle tests stay the reference's FP64 arithmetic.
+struct GpuSahNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t child0, child1;
+    int32_t pad[2];
+};
+static_assert(sizeof(GpuSahNode) == 64, "GpuSahNode must stay 64 bytes");
 
 // Read once per accepted hit / light sample: unit normal and area (triangle.h:26-29).
 struct GpuTriAux {
@@ -62,6 +91,12 @@ struct GpuCamera {
 struct SceneDev {
     const GpuNode* nodes;
     const GpuTri* tris;
+    const GpuWideNode* wnodes;      // ordered-traversal form of the same tree
+    const GpuTri* stris;            // triangles in leaf order; `pad` holds the original triangle id
+    uint32_t n_wnodes;
+    const GpuSahNode* xnodes;       // closest-hit hierarchy (surface-area heuristic, FP32 boxes)
+    const GpuTri* xtris;            // its triangles in its own leaf order; `pad` = position in `stris`
+    uint32_t n_xnodes;
     const GpuTriAux* aux;
     const GpuMaterial* mats;
     const uint32_t* light_tris;     // the light collection (triangle ids, insertion order)

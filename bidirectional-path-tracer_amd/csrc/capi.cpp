@@ -202,8 +202,16 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     wb.ns = ns; wb.shadow_cap = shadow_cap; wb.vis_words = vis_words;
 
     WfLaunchCfg cfg;
-    cfg.lds_scene = scene_fits_lds(scene->dev);
-    cfg.lds_bytes = cfg.lds_scene ? (size_t)scene->dev.n_nodes * sizeof(GpuNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri) : 0;
+    if ((int)scene->host.tree_depth > kWideStackDepth || (int)scene->host.sah_depth > kWideStackDepth)
+        return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+    // per traversal kernel: its own node table + its own triangle order
+    {
+        const size_t shadow_bytes = (size_t)scene->dev.n_wnodes * sizeof(GpuWideNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
+        const size_t extend_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuSahNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
+        cfg.lds_bytes = shadow_bytes > extend_bytes ? shadow_bytes : extend_bytes;
+    }
+    cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
+    if (!cfg.lds_scene) cfg.lds_bytes = 0;
     int per_cu = 1;
     HIP_TRY(wf_persistent_blocks_per_cu(cfg.lds_scene, cfg.lds_bytes, &per_cu));
     cfg.persistent_blocks = ctx->cu_count * per_cu;
@@ -415,7 +423,11 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     // one device allocation, tables at 256-byte aligned offsets
     size_t off_nodes = 0;
     size_t off_tris = off_nodes + align256(h.nodes.size() * sizeof(GpuNode));
-    size_t off_aux = off_tris + align256(h.tris.size() * sizeof(GpuTri));
+    size_t off_wn = off_tris + align256(h.tris.size() * sizeof(GpuTri));
+    size_t off_st = off_wn + align256(h.wnodes.size() * sizeof(GpuWideNode));
+    size_t off_xn = off_st + align256(h.stris.size() * sizeof(GpuTri));
+    size_t off_xt = off_xn + align256(h.xnodes.size() * sizeof(GpuSahNode));
+    size_t off_aux = off_xt + align256(h.xtris.size() * sizeof(GpuTri));
     size_t off_mats = off_aux + align256(h.aux.size() * sizeof(GpuTriAux));
     size_t off_ltri = off_mats + align256(h.mats.size() * sizeof(GpuMaterial));
     size_t off_lacc = off_ltri + align256(h.light_tris.size() * sizeof(uint32_t));
@@ -428,6 +440,10 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     struct { size_t off; const void* src; size_t bytes; } parts[] = {
         {off_nodes, h.nodes.data(), h.nodes.size() * sizeof(GpuNode)},
         {off_tris, h.tris.data(), h.tris.size() * sizeof(GpuTri)},
+        {off_wn, h.wnodes.data(), h.wnodes.size() * sizeof(GpuWideNode)},
+        {off_st, h.stris.data(), h.stris.size() * sizeof(GpuTri)},
+        {off_xn, h.xnodes.data(), h.xnodes.size() * sizeof(GpuSahNode)},
+        {off_xt, h.xtris.data(), h.xtris.size() * sizeof(GpuTri)},
         {off_aux, h.aux.data(), h.aux.size() * sizeof(GpuTriAux)},
         {off_mats, h.mats.data(), h.mats.size() * sizeof(GpuMaterial)},
         {off_ltri, h.light_tris.data(), h.light_tris.size() * sizeof(uint32_t)},
@@ -440,6 +456,12 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     SceneDev& d = s->dev;
     d.nodes = reinterpret_cast<const GpuNode*>(base + off_nodes);
     d.tris = reinterpret_cast<const GpuTri*>(base + off_tris);
+    d.wnodes = reinterpret_cast<const GpuWideNode*>(base + off_wn);
+    d.stris = reinterpret_cast<const GpuTri*>(base + off_st);
+    d.n_wnodes = (uint32_t)h.wnodes.size();
+    d.xnodes = reinterpret_cast<const GpuSahNode*>(base + off_xn);
+    d.xtris = reinterpret_cast<const GpuTri*>(base + off_xt);
+    d.n_xnodes = (uint32_t)h.xnodes.size();
     d.aux = reinterpret_cast<const GpuTriAux*>(base + off_aux);
     d.mats = reinterpret_cast<const GpuMaterial*>(base + off_mats);
     d.light_tris = reinterpret_cast<const uint32_t*>(base + off_ltri);

@@ -91,6 +91,130 @@ struct Builder {
 
 inline double vx(const double* v, int k) { return v[k]; }
 
+
+// ---------------------------------------------------------------------------------------------
+// Binned surface-area-heuristic hierarchy for closest-hit queries.
+struct SahRef { double lo[3], hi[3], c[3]; uint32_t pos; };
+
+inline float round_down(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+inline float round_up(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+
+struct SahBuilder {
+    std::vector<SahRef> refs;
+    std::vector<GpuSahNode> nodes;
+    std::vector<uint32_t> leaf_order;      // positions (in stris) in this hierarchy's leaf order
+    uint32_t max_depth = 0;
+
+    static double area(const double* lo, const double* hi) {
+        const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+    void bounds(size_t a, size_t b, double* lo, double* hi) const {
+        for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<double>::infinity(); hi[k] = -lo[k]; }
+        for (size_t i = a; i < b; i++)
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], refs[i].lo[k]); hi[k] = std::max(hi[k], refs[i].hi[k]); }
+    }
+    int32_t make_leaf(size_t a, size_t b) {
+        const uint32_t first = (uint32_t)leaf_order.size();
+        for (size_t i = a; i < b; i++) leaf_order.push_back(refs[i].pos);
+        return ~(int32_t)((first << 2) | (uint32_t)(b - a - 1));
+    }
+    // returns the child reference of the subtree over refs[a, b)
+    int32_t build(size_t a, size_t b, uint32_t depth) {
+        if (depth > max_depth) max_depth = depth;
+        const size_t n = b - a;
+        if (n <= 2) return make_leaf(a, b);
+        double clo[3], chi[3];
+        for (int k = 0; k < 3; k++) { clo[k] = std::numeric_limits<double>::infinity(); chi[k] = -clo[k]; }
+        for (size_t i = a; i < b; i++)
+            for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], refs[i].c[k]); chi[k] = std::max(chi[k], refs[i].c[k]); }
+        constexpr int kBins = 16;
+        double best_cost = std::numeric_limits<double>::infinity();
+        int best_axis = -1, best_split = 0;
+        for (int axis = 0; axis < 3; axis++) {
+            const double ext = chi[axis] - clo[axis];
+            if (!(ext > 0)) continue;
+            size_t cnt[kBins] = {0};
+            double blo[kBins][3], bhi[kBins][3];
+            for (int q = 0; q < kBins; q++)
+                for (int k = 0; k < 3; k++) { blo[q][k] = std::numeric_limits<double>::infinity(); bhi[q][k] = -blo[q][k]; }
+            const double scale = kBins / ext;
+            for (size_t i = a; i < b; i++) {
+                int q = (int)((refs[i].c[axis] - clo[axis]) * scale);
+                q = q < 0 ? 0 : (q >= kBins ? kBins - 1 : q);
+                cnt[q]++;
+                for (int k = 0; k < 3; k++) { blo[q][k] = std::min(blo[q][k], refs[i].lo[k]); bhi[q][k] = std::max(bhi[q][k], refs[i].hi[k]); }
+            }
+            double right_area[kBins];
+            size_t right_cnt[kBins];
+            double rlo[3], rhi[3];
+            for (int k = 0; k < 3; k++) { rlo[k] = std::numeric_limits<double>::infinity(); rhi[k] = -rlo[k]; }
+            size_t rc = 0;
+            for (int q = kBins - 1; q >= 1; q--) {
+                for (int k = 0; k < 3; k++) { rlo[k] = std::min(rlo[k], blo[q][k]); rhi[k] = std::max(rhi[k], bhi[q][k]); }
+                rc += cnt[q];
+                right_area[q] = rc ? area(rlo, rhi) : 0.0;
+                right_cnt[q] = rc;
+            }
+            double llo[3], lhi[3];
+            for (int k = 0; k < 3; k++) { llo[k] = std::numeric_limits<double>::infinity(); lhi[k] = -llo[k]; }
+            size_t lc = 0;
+            for (int q = 0; q < kBins - 1; q++) {
+                for (int k = 0; k < 3; k++) { llo[k] = std::min(llo[k], blo[q][k]); lhi[k] = std::max(lhi[k], bhi[q][k]); }
+                lc += cnt[q];
+                if (lc == 0 || right_cnt[q + 1] == 0) continue;
+                const double cost = area(llo, lhi) * (double)lc + right_area[q + 1] * (double)right_cnt[q + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = q + 1; }
+            }
+        }
+        size_t mid;
+        if (best_axis < 0) {
+            if (n <= 4) return make_leaf(a, b);
+            mid = a + n / 2;                               // all centroids coincide
+        } else {
+            double lo[3], hi[3];
+            bounds(a, b, lo, hi);
+            const double parent = area(lo, hi);
+            // leaf cost n * 1.0 against split cost 1.0 + children (box test taken as one triangle test)
+            if (n <= 4 && parent > 0 && best_cost / parent + 1.0 >= (double)n) return make_leaf(a, b);
+            const double ext = chi[best_axis] - clo[best_axis];
+            const double scale = kBins / ext;
+            const double c0 = clo[best_axis];
+            const int axis = best_axis, split = best_split;
+            auto it = std::partition(refs.begin() + a, refs.begin() + b, [=](const SahRef& r) {
+                int q = (int)((r.c[axis] - c0) * scale);
+                q = q < 0 ? 0 : (q >= kBins ? kBins - 1 : q);
+                return q < split;
+            });
+            mid = (size_t)(it - refs.begin());
+            if (mid == a || mid == b) mid = a + n / 2;
+        }
+        const int32_t idx = (int32_t)nodes.size();
+        nodes.push_back(GpuSahNode());
+        double lo0[3], hi0[3], lo1[3], hi1[3];
+        bounds(a, mid, lo0, hi0);
+        bounds(mid, b, lo1, hi1);
+        const int32_t c0r = build(a, mid, depth + 1);
+        const int32_t c1r = build(mid, b, depth + 1);
+        GpuSahNode& nd = nodes[idx];
+        for (int k = 0; k < 3; k++) {
+            nd.lo0[k] = round_down(lo0[k]); nd.hi0[k] = round_up(hi0[k]);
+            nd.lo1[k] = round_down(lo1[k]); nd.hi1[k] = round_up(hi1[k]);
+        }
+        nd.child0 = c0r; nd.child1 = c1r;
+        nd.pad[0] = nd.pad[1] = 0;
+        return idx;
+    }
+};
+
 }  // namespace
 
 std::string build_host_scene(const double* tv, const int32_t* tri_material, uint32_t n_tri,
@@ -183,6 +307,93 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
             g.tri1 = ~n.right;
             out.dfs_leaves.push_back((uint32_t)g.tri0);
             out.dfs_leaves.push_back((uint32_t)g.tri1);
+        }
+    }
+
+    // wide records for ordered traversal: interior nodes in pre-order, triangles in leaf order
+    {
+        std::vector<uint32_t> pos_of(n_tri, 0);
+        out.stris.reserve(n_tri);
+        for (size_t k = 0; k < out.dfs_leaves.size(); k++) {
+            const uint32_t id = out.dfs_leaves[k];
+            if (k > 0 && out.dfs_leaves[k - 1] == id && (k & 1)) continue;      // second mention by a one-triangle node
+            pos_of[id] = (uint32_t)out.stris.size();
+            GpuTri t = out.tris[id];
+            t.pad = (int32_t)id;
+            out.stris.push_back(t);
+        }
+        std::vector<int32_t> wide_index(n_nodes, -1);
+        int32_t n_wide = 0;
+        for (uint32_t i = 0; i < n_nodes; i++) if (b.nodes[i].left >= 0) wide_index[i] = n_wide++;
+        auto child_ref = [&](int32_t node) -> int32_t {
+            const BuildNode& n = b.nodes[node];
+            if (n.left >= 0) return wide_index[node];
+            const uint32_t t0 = (uint32_t)~n.left, t1 = (uint32_t)~n.right;
+            const uint32_t code = (pos_of[t0] << 2) | (t1 != t0 ? 1u : 0u);
+            return ~(int32_t)code;
+        };
+        const double inf = std::numeric_limits<double>::infinity();
+        if (n_wide == 0) {                      // the root's children are triangles: wrap it in one record
+            GpuWideNode w{};
+            for (int k = 0; k < 3; k++) { w.lo0[k] = b.nodes[0].box.lo[k]; w.hi0[k] = b.nodes[0].box.hi[k]; w.lo1[k] = inf; w.hi1[k] = -inf; }
+            w.child0 = child_ref(0);
+            w.child1 = ~(int32_t)0;
+            out.wnodes.push_back(w);
+        } else {
+            out.wnodes.resize(n_wide);
+            for (uint32_t i = 0; i < n_nodes; i++) {
+                const BuildNode& n = b.nodes[i];
+                if (n.left < 0) continue;
+                GpuWideNode w{};
+                const Box3& b0 = b.nodes[n.left].box;
+                const Box3& b1 = b.nodes[n.right].box;
+                for (int k = 0; k < 3; k++) { w.lo0[k] = b0.lo[k]; w.hi0[k] = b0.hi[k]; w.lo1[k] = b1.lo[k]; w.hi1[k] = b1.hi[k]; }
+                w.child0 = child_ref(n.left);
+                w.child1 = child_ref(n.right);
+                out.wnodes[wide_index[i]] = w;
+            }
+        }
+    }
+
+    // closest-hit hierarchy over the same triangles (referenced by their position in `stris`)
+    {
+        SahBuilder sb;
+        sb.refs.resize(out.stris.size());
+        for (size_t p = 0; p < out.stris.size(); p++) {
+            const uint32_t id = (uint32_t)out.stris[p].pad;
+            SahRef& r = sb.refs[p];
+            r.pos = (uint32_t)p;
+            for (int k = 0; k < 3; k++) {
+                // the triangle's exact box, padded on every axis: at least the reference's own padding of
+                // thin boxes (aabb.h:81-88), and well above the rounding of an accepted hit point
+                const double pad = std::fmax(5e-5, 1e-9 * std::fmax(std::fabs(btris[id].box.lo[k]), std::fabs(btris[id].box.hi[k])));
+                r.lo[k] = btris[id].box.lo[k] - pad;
+                r.hi[k] = btris[id].box.hi[k] + pad;
+                r.c[k] = 0.5 * (r.lo[k] + r.hi[k]);
+            }
+        }
+        sb.nodes.reserve(out.stris.size());
+        sb.leaf_order.reserve(out.stris.size());
+        int32_t root = sb.build(0, sb.refs.size(), 1);
+        if (root < 0) {                        // one leaf only: wrap it so that record 0 exists
+            GpuSahNode w{};
+            double lo[3], hi[3];
+            sb.bounds(0, sb.refs.size(), lo, hi);
+            for (int k = 0; k < 3; k++) {
+                w.lo0[k] = round_down(lo[k]); w.hi0[k] = round_up(hi[k]);
+                w.lo1[k] = std::numeric_limits<float>::infinity(); w.hi1[k] = -std::numeric_limits<float>::infinity();
+            }
+            w.child0 = root;
+            w.child1 = ~(int32_t)0;
+            sb.nodes.push_back(w);
+        }
+        out.xnodes = sb.nodes;
+        out.sah_depth = sb.max_depth;
+        out.xtris.resize(sb.leaf_order.size());
+        for (size_t k = 0; k < sb.leaf_order.size(); k++) {
+            GpuTri t = out.stris[sb.leaf_order[k]];
+            t.pad = (int32_t)sb.leaf_order[k];
+            out.xtris[k] = t;
         }
     }
 

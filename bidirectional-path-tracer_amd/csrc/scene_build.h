@@ -15,6 +15,11 @@ namespace bdpt {
 struct HostScene {
     std::vector<GpuNode> nodes;          // pre-order (root first); links already threaded
     std::vector<GpuTri> tris;
+    std::vector<GpuWideNode> wnodes;     // interior nodes in pre-order, both child boxes per record
+    std::vector<GpuTri> stris;           // triangles in leaf order (pad = original id)
+    std::vector<GpuSahNode> xnodes;      // closest-hit hierarchy (binned SAH)
+    std::vector<GpuTri> xtris;           // its triangles in leaf order (pad = position in stris)
+    uint32_t sah_depth = 0;
     std::vector<GpuTriAux> aux;
     std::vector<GpuMaterial> mats;
     std::vector<uint32_t> light_tris;

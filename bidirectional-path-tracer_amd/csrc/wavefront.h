@@ -32,6 +32,9 @@ struct WfBuffers {
     uint32_t vis_words;
 };
 
+// per-lane stack of the ordered walk (one entry per tree level at most)
+constexpr int kWideStackDepth = 40;
+
 constexpr uint32_t kCntEyeHit = 1u << 24, kCntLightHit = 1u << 25, kCntLightValid = 1u << 26;
 
 struct WfBatch {

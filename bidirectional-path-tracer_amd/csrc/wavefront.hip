@@ -66,18 +66,6 @@ BDPT_DEV VertexStore slot_store(const WfBuffers& wb, uint32_t slot) {
     return st;
 }
 
-BDPT_DEV void stage_scene(const SceneDev& sc, GpuNode* l_nodes, GpuTri* l_tris) {
-    const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
-    uint4* dst = reinterpret_cast<uint4*>(l_nodes);
-    const uint32_t n16 = sc.n_nodes * (sizeof(GpuNode) / 16);
-    for (uint32_t k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
-    src = reinterpret_cast<const uint4*>(sc.tris);
-    dst = reinterpret_cast<uint4*>(l_tris);
-    const uint32_t t16 = sc.n_tris * (sizeof(GpuTri) / 16);
-    for (uint32_t k = threadIdx.x; k < t16; k += blockDim.x) dst[k] = src[k];
-    __syncthreads();
-}
-
 // ------------------------------------------------------------------ camera rays
 __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb, WfBatch b) {
     const uint32_t spp = (uint32_t)(cam.sqrt_spp * cam.sqrt_spp);
@@ -108,21 +96,73 @@ __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb,
 }
 
 // ------------------------------------------------------------------ persistent traversal
-// One loop iteration = one node visit of every lane that holds a ray.  SHADOW: rays come from the
-// shadow queue, the walk stops at the first hit and a clear ray sets its pair's visibility bit.
+// Ordered (near child first) walk over the wide records with a small per-lane stack.
+//
+// Why a different visiting order still returns the reference's answer:
+//  * every box test is the reference's test (same FP64 box, same slab arithmetic, the running
+//    closest t as upper bound), and a triangle is accepted by the reference's inclusive interval
+//    test (triangle.h:63);
+//  * shadow rays: the upper bound never changes before the first accepted triangle, so the set of
+//    boxes that pass - and therefore whether ANY triangle is accepted - does not depend on the order;
+//  * closest-hit rays: the reference keeps, among equal t, the triangle it visits last (bvh.h:55-56),
+//    i.e. the one later in its left-to-right leaf order; triangles are stored in that order, so the
+//    tie is broken by position.  Culling against a closer bound found earlier only removes boxes that
+//    lie entirely behind that bound.
+//  * the root's own box (bvh.h:52 at the root) is not tested separately: it contains both child
+//    boxes, and the slab arithmetic is monotone, so a ray that passes a child box passes the root box.
+constexpr int kStackDepth = kWideStackDepth;
+constexpr int32_t kPop = (int32_t)0x80000000;   // neither an interior index (>= 0) nor a leaf reference
+
+template <class NodeT>
+struct TreeMem {
+    const NodeT* wn;          // global or LDS copy
+    const GpuTri* st;
+    BDPT_DEV NodeT wnode(int32_t i) const { return wn[i]; }
+    BDPT_DEV GpuTri stri(uint32_t i) const { return st[i]; }
+};
+
+template <class T>
+BDPT_DEV void slab(const T* blo, const T* bhi, V3 o, double ix, double iy, double iz, double closest, double& lo,
+                   double& hi) {
+    lo = 0.001; hi = closest;
+    {
+        double t0 = ((double)blo[0] - o.x) * ix, t1 = ((double)bhi[0] - o.x) * ix;
+        double nr = (t0 < t1) ? t0 : t1, fr = (t0 < t1) ? t1 : t0;
+        lo = (nr > lo) ? nr : lo; hi = (fr < hi) ? fr : hi;
+    }
+    {
+        double t0 = ((double)blo[1] - o.y) * iy, t1 = ((double)bhi[1] - o.y) * iy;
+        double nr = (t0 < t1) ? t0 : t1, fr = (t0 < t1) ? t1 : t0;
+        lo = (nr > lo) ? nr : lo; hi = (fr < hi) ? fr : hi;
+    }
+    {
+        double t0 = ((double)blo[2] - o.z) * iz, t1 = ((double)bhi[2] - o.z) * iz;
+        double nr = (t0 < t1) ? t0 : t1, fr = (t0 < t1) ? t1 : t0;
+        lo = (nr > lo) ? nr : lo; hi = (fr < hi) ? fr : hi;
+    }
+}
+
+// One loop iteration = one record (or leaf) visit of every lane that holds a ray.  SHADOW: rays come
+// from the shadow queue, the walk stops at the first accepted triangle and a clear ray sets its
+// pair's visibility bit.
 template <bool SHADOW, bool STATS, class Mem>
-BDPT_DEV void traverse_queue(const Mem& mem, const WfBuffers& wb, const uint32_t* queue, uint32_t count, uint32_t* cursor,
-                             unsigned long long* stats) {
+BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffers& wb, const uint32_t* queue, uint32_t count,
+                             uint32_t* cursor, unsigned long long* stats) {
     bool has = false;
-    uint32_t slot = 0, node = 0;
+    uint32_t slot = 0;
+    int32_t cur = kPop;
+    int sp = 0;
+    int32_t stk_node[kStackDepth];
+    double stk_lo[kStackDepth];
     unsigned long long tag = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
-    double ix = 0, iy = 0, iz = 0, closest = 0, tmax0 = 0;
+    double ix = 0, iy = 0, iz = 0, closest = 0;
     HitLite h;
     h.t = 0; h.u = 0; h.v = 0; h.tri = -1;
+    int32_t best_pos = -1;
     uint32_t pool_next = 0, pool_end = 0;     // wave-uniform
     bool exhausted = (count == 0);
-    uint32_t n_nodes = 0, n_box_hits = 0, n_tri = 0, n_tri_hits = 0;
+    uint32_t n_records = 0, n_box_hits = 0, n_tri = 0, n_tri_hits = 0, n_rays = 0;
 
     for (;;) {
         const unsigned long long idle = __ballot(!has);
@@ -141,6 +181,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const WfBuffers& wb, const uint32_t
                 const uint32_t r = rank_in_mask(idle);
                 if (r < give) {
                     const uint32_t k = pool_next + r;
+                    double tmax0;
                     if (SHADOW) {
                         const uint64_t cap = wb.shadow_cap;
                         o = mk(wb.shadow[k], wb.shadow[cap + k], wb.shadow[2 * cap + k]);
@@ -154,11 +195,16 @@ BDPT_DEV void traverse_queue(const Mem& mem, const WfBuffers& wb, const uint32_t
                         d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
                         tmax0 = kInf;
                     }
-                    ix = 1.0 / d.x; iy = 1.0 / d.y; iz = 1.0 / d.z;       // aabb.h:48, once per ray
-                    closest = tmax0;
-                    node = 0;
-                    h.tri = -1;
-                    has = true;
+                    if (!SHADOW || tmax0 >= 0.0) {              // a negative max_t marks an unused queue entry
+                        ix = 1.0 / d.x; iy = 1.0 / d.y; iz = 1.0 / d.z;       // aabb.h:48, once per ray
+                        closest = tmax0;
+                        cur = 0;
+                        sp = 0;
+                        h.tri = -1;
+                        best_pos = -1;
+                        has = true;
+                        if (STATS) n_rays++;
+                    }
                 }
             }
             pool_next += give;
@@ -168,47 +214,56 @@ BDPT_DEV void traverse_queue(const Mem& mem, const WfBuffers& wb, const uint32_t
             continue;
         }
         if (has) {
-            const GpuNode nd = mem.node(node);
-            if (STATS) n_nodes++;
-            double lo = 0.001, hi = closest;
-            {
-                double t0 = (nd.lo[0] - o.x) * ix, t1 = (nd.hi[0] - o.x) * ix;
-                double nr = (t0 < t1) ? t0 : t1, fr = (t0 < t1) ? t1 : t0;
-                lo = (nr > lo) ? nr : lo; hi = (fr < hi) ? fr : hi;
-            }
-            {
-                double t0 = (nd.lo[1] - o.y) * iy, t1 = (nd.hi[1] - o.y) * iy;
-                double nr = (t0 < t1) ? t0 : t1, fr = (t0 < t1) ? t1 : t0;
-                lo = (nr > lo) ? nr : lo; hi = (fr < hi) ? fr : hi;
-            }
-            {
-                double t0 = (nd.lo[2] - o.z) * iz, t1 = (nd.hi[2] - o.z) * iz;
-                double nr = (t0 < t1) ? t0 : t1, fr = (t0 < t1) ? t1 : t0;
-                lo = (nr > lo) ? nr : lo; hi = (fr < hi) ? fr : hi;
-            }
             bool done = false;
-            if (hi <= lo) {
-                node = nd.skip;
+            if (cur >= 0) {
+                const auto nd = mem.wnode(cur);
+                if (STATS) n_records++;
+                double lo0, hi0, lo1, hi1;
+                slab(nd.lo0, nd.hi0, o, ix, iy, iz, closest, lo0, hi0);
+                slab(nd.lo1, nd.hi1, o, ix, iy, iz, closest, lo1, hi1);
+                const bool p0 = !(hi0 <= lo0), p1 = !(hi1 <= lo1);
+                if (STATS) n_box_hits += (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
+                if (p0 && p1) {
+                    const bool second_first = lo1 < lo0;
+                    const int32_t near_c = second_first ? nd.child1 : nd.child0;
+                    const int32_t far_c = second_first ? nd.child0 : nd.child1;
+                    const double far_lo = second_first ? lo0 : lo1;
+                    stk_node[sp] = far_c; stk_lo[sp] = far_lo;      // sp < tree depth <= kStackDepth (checked by the host)
+                    sp++;
+                    cur = near_c;
+                } else if (p0) cur = nd.child0;
+                else if (p1) cur = nd.child1;
+                else cur = kPop;
             } else {
-                if (STATS) n_box_hits++;
-                if (nd.tri0 >= 0) {
+                const uint32_t code = (uint32_t)~cur;
+                const uint32_t first = code >> 2;
+                const uint32_t n_here = 1u + (code & 3u);
+                for (uint32_t q = 0; q < n_here; q++) {
+                    const GpuTri tr = mem.stri(first + q);
                     double t, u, v;
-                    {
-                        const GpuTri tr = mem.tri(nd.tri0);
-                        const bool hit = tri_test(tr, o, d, 0.001, closest, t, u, v);
-                        if (STATS) { n_tri++; if (hit) n_tri_hits++; }
-                        if (hit) { closest = t; h.t = t; h.u = u; h.v = v; h.tri = nd.tri0; if (SHADOW) done = true; }
-                    }
-                    if (nd.tri1 != nd.tri0 && !done) {
-                        const GpuTri tr = mem.tri(nd.tri1);
-                        const bool hit = tri_test(tr, o, d, 0.001, closest, t, u, v);
-                        if (STATS) { n_tri++; if (hit) n_tri_hits++; }
-                        if (hit) { closest = t; h.t = t; h.u = u; h.v = v; h.tri = nd.tri1; if (SHADOW) done = true; }
+                    // triangle.h:63: accepted when tmin <= t <= closest (inclusive)
+                    const bool inside = tri_test(tr, o, d, 0.001, closest, t, u, v);
+                    if (STATS) { n_tri++; if (inside) n_tri_hits++; }
+                    if (inside) {
+                        if (SHADOW) { h.tri = tr.pad; done = true; break; }
+                        // equal t: the reference keeps the triangle it visits later = larger position in
+                        // its leaf order (tr.pad)
+                        if (t < closest || best_pos < 0 || tr.pad > best_pos) {
+                            closest = t; h.t = t; h.u = u; h.v = v; best_pos = tr.pad; h.tri = tr.pad;
+                        }
                     }
                 }
-                node = nd.next;
+                cur = kPop;
             }
-            if (node == kEndOfTree) done = true;
+            if (!done && cur == kPop) {
+                done = true;
+                while (sp > 0) {
+                    sp--;
+                    const double e_lo = stk_lo[sp];
+                    const int32_t e_node = stk_node[sp];
+                    if (!(closest <= e_lo)) { cur = e_node; done = false; break; }    // aabb.h:61 with the current bound
+                }
+            }
             if (done) {
                 if (SHADOW) {
                     if (h.tri < 0) {       // nothing in the way: the pair is visible
@@ -218,7 +273,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const WfBuffers& wb, const uint32_t
                     }
                 } else {
                     const uint64_t ns = wb.ns;
-                    wb.hit_tri[slot] = h.tri;
+                    wb.hit_tri[slot] = (h.tri >= 0) ? stris[h.tri].pad : -1;      // leaf position -> triangle id
                     if (h.tri >= 0) { wb.hit[slot] = h.t; wb.hit[ns + slot] = h.u; wb.hit[2 * ns + slot] = h.v; }
                 }
                 has = false;
@@ -226,32 +281,59 @@ BDPT_DEV void traverse_queue(const Mem& mem, const WfBuffers& wb, const uint32_t
         }
     }
     if (STATS) {
-        flush_wave_counter(&stats[1], n_nodes);
+        flush_wave_counter(&stats[SHADOW ? 6 : 0], n_rays);
+        flush_wave_counter(&stats[1], 2ull * n_records);
         flush_wave_counter(&stats[2], n_box_hits);
-        flush_wave_counter(&stats[3], n_nodes);
+        flush_wave_counter(&stats[3], (SHADOW ? 2ull : 1ull) * n_records);   // in units of 64 bytes fetched
         flush_wave_counter(&stats[4], n_tri);
         flush_wave_counter(&stats[5], n_tri_hits);
     }
 }
 
+template <class NodeT>
+BDPT_DEV void stage_tree(const NodeT* nodes, uint32_t n_nodes, const GpuTri* tris, uint32_t n_tris, NodeT* l_nodes, GpuTri* l_tris) {
+    const uint4* src = reinterpret_cast<const uint4*>(nodes);
+    uint4* dst = reinterpret_cast<uint4*>(l_nodes);
+    const uint32_t n16 = n_nodes * (uint32_t)(sizeof(NodeT) / 16);
+    for (uint32_t k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
+    src = reinterpret_cast<const uint4*>(tris);
+    dst = reinterpret_cast<uint4*>(l_tris);
+    const uint32_t t16 = n_tris * (uint32_t)(sizeof(GpuTri) / 16);
+    for (uint32_t k = threadIdx.x; k < t16; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+}
+
+// SHADOW walks the reference's own tree (GpuWideNode): whether a visibility query is blocked depends on
+// that tree's boxes.  Closest-hit queries walk the surface-area-heuristic hierarchy (GpuSahNode).
 template <bool SHADOW, bool STATS, bool LDS_SCENE>
 __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
                                                      const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                      unsigned long long* stats) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
-    if (LDS_SCENE) {
-        GpuNode* l_nodes = reinterpret_cast<GpuNode*>(smem);
-        GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_nodes);
-        stage_scene(sc, l_nodes, l_tris);
-        LdsScene mem{l_nodes, l_tris};
-        traverse_queue<SHADOW, STATS>(mem, wb, queue, count, cursor, stats);
+    if (SHADOW) {
+        if (LDS_SCENE) {
+            GpuWideNode* l_nodes = reinterpret_cast<GpuWideNode*>(smem);
+            GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_wnodes);
+            stage_tree(sc.wnodes, sc.n_wnodes, sc.stris, sc.n_tris, l_nodes, l_tris);
+            TreeMem<GpuWideNode> mem{l_nodes, l_tris};
+            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats);
+        } else {
+            TreeMem<GpuWideNode> mem{sc.wnodes, sc.stris};
+            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats);
+        }
     } else {
-        GlobalScene mem{sc.nodes, sc.tris};
-        traverse_queue<SHADOW, STATS>(mem, wb, queue, count, cursor, stats);
+        if (LDS_SCENE) {
+            GpuSahNode* l_nodes = reinterpret_cast<GpuSahNode*>(smem);
+            GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
+            stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
+            TreeMem<GpuSahNode> mem{l_nodes, l_tris};
+            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats);
+        } else {
+            TreeMem<GpuSahNode> mem{sc.xnodes, sc.xtris};
+            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats);
+        }
     }
-    if (STATS && !SHADOW && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)count);
-    if (STATS && SHADOW && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[6], (unsigned long long)count);
 }
 
 // ------------------------------------------------------------------ shading of one bounce
@@ -382,15 +464,22 @@ __global__ __launch_bounds__(kBlock) void k_conn_prepare(GpuCamera cam, WfBuffer
     if (STATS) { flush_wave_counter(&stats[8], draws); flush_wave_counter(&stats[9], samples); }
 }
 
-// shadow rays of eye vertex `a` against every light vertex of the sample
+// shadow rays of eye vertex `a` against every light vertex of the sample.  Queue space is reserved
+// once per 1024-thread workgroup (one atomic) for every candidate pair; pairs that turn out to
+// contribute nothing without a ray leave an entry with a negative max_t, which the traversal skips.
+constexpr int kConnBlock = 1024;
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_conn_gen(SceneDev sc, GpuCamera cam, WfBuffers wb, int a, const uint32_t* conn_count,
-                                                     uint32_t* shadow_count, unsigned long long* stats) {
+__global__ __launch_bounds__(kConnBlock) void k_conn_gen(SceneDev sc, GpuCamera cam, WfBuffers wb, int a,
+                                                         const uint32_t* conn_count, uint32_t* shadow_count,
+                                                         unsigned long long* stats) {
+    __shared__ uint32_t s_wave_off[kConnBlock / 64];
+    __shared__ uint32_t s_base;
     const uint32_t count = *conn_count;
     const int depth = cam.max_depth;
-    const uint32_t rounded = (count + 63u) & ~63u;
+    const uint32_t rounded = (count + (kConnBlock - 1)) & ~(uint32_t)(kConnBlock - 1);
+    const uint32_t wave = threadIdx.x >> 6;
     uint32_t n_pairs = 0;
-    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < rounded; k += gridDim.x * kBlock) {
+    for (uint32_t k = blockIdx.x * kConnBlock + threadIdx.x; k < rounded; k += gridDim.x * kConnBlock) {
         uint32_t slot = 0;
         int n_light = 0;
         Vertex cv;
@@ -408,33 +497,39 @@ __global__ __launch_bounds__(kBlock) void k_conn_gen(SceneDev sc, GpuCamera cam,
                 cam_ok = !(cv.info & kVtxIsLight);
             }
         }
-        const int max_light = cam_ok ? n_light : 0;
-        int wave_max = max_light;
+        const uint32_t mine = cam_ok ? (uint32_t)n_light : 0u;
+        // workgroup-wide exclusive scan of `mine`
+        uint32_t incl = mine;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { int o2 = __shfl_xor(wave_max, off, 64); wave_max = o2 > wave_max ? o2 : wave_max; }
-        for (int bi = 0; bi < wave_max; bi++) {
-            bool emit = false;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if ((int)lane_id() >= off) incl += v;
+        }
+        if (lane_id() == 63) s_wave_off[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int w = 0; w < kConnBlock / 64; w++) { const uint32_t t = s_wave_off[w]; s_wave_off[w] = run; run += t; }
+            s_base = run ? atomicAdd(shadow_count, run) : 0u;
+        }
+        __syncthreads();
+        uint64_t e = (uint64_t)s_base + s_wave_off[wave] + incl - mine;
+        const uint64_t cap = wb.shadow_cap;
+        for (uint32_t bi = 0; bi < mine; bi++, e++) {
+            const Vertex lv = slot_store(wb, slot).get(depth + (int)bi);
             PairGeom g;
-            if (bi < max_light) {
-                const Vertex lv = slot_store(wb, slot).get(depth + bi);
-                V3 f_cam, f_light;
-                emit = pair_geometry(cv, lv, g) && pair_factors(sc, cv, lv, f_cam, f_light);
-            }
-            const unsigned long long m = __ballot(emit);
-            if (m == 0) continue;
-            uint32_t base = 0;
-            const int leader = __builtin_ctzll(m);
-            if ((int)lane_id() == leader) base = atomicAdd(shadow_count, (uint32_t)__builtin_popcountll(m));
-            base = __shfl(base, leader, 64);
+            V3 f_cam, f_light;
+            const bool emit = pair_geometry(cv, lv, g) && pair_factors(sc, cv, lv, f_cam, f_light);
             if (emit) {
-                const uint64_t e = base + rank_in_mask(m);
-                const uint64_t cap = wb.shadow_cap;
                 wb.shadow[e] = g.origin.x; wb.shadow[cap + e] = g.origin.y; wb.shadow[2 * cap + e] = g.origin.z;
                 wb.shadow[3 * cap + e] = g.dir_unit.x; wb.shadow[4 * cap + e] = g.dir_unit.y; wb.shadow[5 * cap + e] = g.dir_unit.z;
                 wb.shadow[6 * cap + e] = g.max_t;
-                wb.shadow[7 * cap + e] = __longlong_as_double((long long)(((unsigned long long)slot << 16) | (unsigned)bi));
+                wb.shadow[7 * cap + e] = __longlong_as_double((long long)(((unsigned long long)slot << 16) | bi));
+            } else {
+                wb.shadow[6 * cap + e] = -1.0;
             }
         }
+        __syncthreads();
     }
     if (STATS) flush_wave_counter(&stats[7], n_pairs);
 }
@@ -560,7 +655,7 @@ hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBa
 
 hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
                        uint32_t* shadow_count, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    dim3 grid(cfg.stream_blocks), block(kBlock);
+    dim3 grid(cfg.stream_blocks / 2), block(kConnBlock);
     if (stats) hipLaunchKernelGGL((k_conn_gen<true>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
     else hipLaunchKernelGGL((k_conn_gen<false>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
     return hipGetLastError();

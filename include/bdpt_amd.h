@@ -111,7 +111,7 @@ typedef struct bdpt_stats {
     uint64_t rays_traced;       /* closest-hit queries of trace_path (camera.h:334) */
     uint64_t aabb_tests;
     uint64_t aabb_hits;
-    uint64_t bvh_node_visits;
+    uint64_t bvh_node_visits;   /* with BDPT_RENDER_COUNT_WORK: node records fetched, in units of 64 bytes */
     uint64_t triangle_tests;
     uint64_t triangle_hits;
     uint64_t shadow_rays;       /* visibility queries that reached the BVH (camera.h:437) */
