@@ -43,6 +43,8 @@ WORKLOADS = {
                              "glass-of-water.yaml camera/materials/light on the procedural stand-in geometry, 1920x1080, 1024 spp, max depth 12"),
     "cornell-512": ("cornell_box", dict(image_width=512, samples_per_pixel=256, max_depth=10),
                     "Cornell box (24 triangles, diffuse + emissive), 512x512, 256 spp, max depth 10"),
+    "glass-of-water-1080p-16spp": ("glass_of_water_standin", dict(image_width=1920, image_height=1080, samples_per_pixel=16, max_depth=12),
+                                   "glass-of-water stand-in, 1920x1080, 16 spp, max depth 12 (profiling size)"),
     "glass-of-water-256": ("glass_of_water_standin", dict(image_width=256, image_height=256, samples_per_pixel=16, max_depth=4),
                            "glass-of-water stand-in, 256x256, 16 spp, max depth 4"),
 }

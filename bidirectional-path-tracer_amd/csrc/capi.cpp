@@ -38,6 +38,8 @@ int hip_fail(hipError_t e, const char* what) {
 
 constexpr int kBlock = 256;
 constexpr int kStatWords = 11;
+constexpr int kWfStreams = 4;                               // batches in flight (one HIP stream each)
+constexpr size_t kWfWorkspaceBudget = (size_t)48 << 30;     // bytes of wavefront state for all of them
 
 }  // namespace
 
@@ -57,6 +59,9 @@ struct bdpt_context {
     // wavefront workspace (one allocation, carved into the WfBuffers arrays)
     void* wf_blob = nullptr;
     size_t wf_blob_bytes = 0;
+    hipStream_t wf_streams[kWfStreams] = {};
+    hipEvent_t wf_fork = nullptr;
+    hipEvent_t wf_join[kWfStreams] = {};
 };
 
 struct bdpt_scene {
@@ -154,6 +159,10 @@ int render_megakernel(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_cam
 }
 
 // ---- wavefront pipeline: batches of samples stream through per-stage kernels (wavefront.h)
+// Several batches are in flight at once, each on its own internal stream with its own workspace:
+// every bounce of a batch ends with the few longest rays of that bounce, and while one batch sits in
+// such a tail the waves of the other batches keep the chip busy.  Nothing in the pipeline waits for
+// the host: kernels whose queue turned out empty return at once.
 int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, uint64_t seed, int x0, int x1,
                      int64_t n_owned, double* d_fb, int stats_mode, hipStream_t stream) {
     const int depth = cam->max_depth;
@@ -161,20 +170,27 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const size_t vslots = 2 * (size_t)(depth > 0 ? depth : 1);
     const uint32_t vis_words = (uint32_t)((depth > 0 ? depth : 1) + 63) / 64;
     const size_t shadow_per_slot = (size_t)(depth > 0 ? depth : 1);
+    if ((int)scene->host.tree_depth > kWideStackDepth || (int)scene->host.sah_depth > kWideStackDepth)
+        return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+    if (n_owned >= ((int64_t)1 << 31)) return fail(BDPT_ERR_UNSUPPORTED, "more than 2^31 pixels in one call");
     // bytes of state per sample slot
     const size_t per_slot = sizeof(double) * (6 + 3 + 3 + 3) + sizeof(uint32_t) * 6 + vslots * 10 * sizeof(double) +
                             vis_words * sizeof(unsigned long long) + shadow_per_slot * 8 * sizeof(double);
-    const size_t budget = (size_t)16 << 30;                     // of 288 GB
-    int64_t ns_target = (int64_t)(budget / per_slot);
+    const size_t budget = (size_t)kWfWorkspaceBudget;           // for all batches in flight, of 288 GB
+    int64_t ns_target = (int64_t)(budget / kWfStreams / per_slot);
     if (ns_target > ((int64_t)1 << 22)) ns_target = (int64_t)1 << 22;
     if (spp > ns_target) return fail(BDPT_ERR_UNSUPPORTED, "samples per pixel exceed the wavefront batch capacity");
     int64_t pixels_per_batch = ns_target / spp;
-    if (pixels_per_batch > n_owned) pixels_per_batch = n_owned;
+    // small renders: still split over the streams so that the tails overlap
+    const int64_t even_share = (n_owned + kWfStreams - 1) / kWfStreams;
+    if (pixels_per_batch > even_share) pixels_per_batch = even_share > 0 ? even_share : 1;
     const uint64_t ns = (uint64_t)(pixels_per_batch * spp);
     const uint64_t shadow_cap = ns * shadow_per_slot;
     const size_t n_counters = 8 + 6 * (size_t)(depth > 0 ? depth : 1);
+    const int64_t n_batches = (n_owned + pixels_per_batch - 1) / pixels_per_batch;
+    const int n_streams = (int)(n_batches < kWfStreams ? n_batches : kWfStreams);
 
-    // carve the workspace
+    // carve one workspace per stream
     size_t off = 0;
     auto take = [&off](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
     const size_t o_ray = take(ns * 6 * 8), o_thr = take(ns * 3 * 8), o_hit = take(ns * 3 * 8), o_res = take(ns * 3 * 8);
@@ -182,30 +198,32 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const size_t o_q0 = take(ns * 4), o_q1 = take(ns * 4), o_cq = take(ns * 4);
     const size_t o_vtx = take(ns * vslots * 10 * 8), o_vis = take(ns * vis_words * 8), o_sh = take(shadow_cap * 8 * 8);
     const size_t o_counters = take(n_counters * 4);
-    if (ctx->wf_blob_bytes < off) {
+    const size_t per_stream = off;
+    const size_t need = per_stream * (size_t)n_streams;
+    if (ctx->wf_blob_bytes < need) {
         if (ctx->wf_blob) (void)hipFree(ctx->wf_blob);
         ctx->wf_blob = nullptr;
         ctx->wf_blob_bytes = 0;
-        HIP_TRY(hipMalloc(&ctx->wf_blob, off));
-        ctx->wf_blob_bytes = off;
+        HIP_TRY(hipMalloc(&ctx->wf_blob, need));
+        ctx->wf_blob_bytes = need;
     }
-    char* base = static_cast<char*>(ctx->wf_blob);
-    WfBuffers wb;
-    wb.ray = reinterpret_cast<double*>(base + o_ray); wb.thr = reinterpret_cast<double*>(base + o_thr);
-    wb.hit = reinterpret_cast<double*>(base + o_hit); wb.result = reinterpret_cast<double*>(base + o_res);
-    wb.hit_tri = reinterpret_cast<int32_t*>(base + o_tri); wb.ctr = reinterpret_cast<uint32_t*>(base + o_ctr);
-    wb.counts = reinterpret_cast<uint32_t*>(base + o_cnt);
-    wb.queue[0] = reinterpret_cast<uint32_t*>(base + o_q0); wb.queue[1] = reinterpret_cast<uint32_t*>(base + o_q1);
-    wb.conn_queue = reinterpret_cast<uint32_t*>(base + o_cq);
-    wb.vtx = reinterpret_cast<double*>(base + o_vtx); wb.vis = reinterpret_cast<unsigned long long*>(base + o_vis);
-    wb.shadow = reinterpret_cast<double*>(base + o_sh); wb.counters = reinterpret_cast<uint32_t*>(base + o_counters);
-    wb.ns = ns; wb.shadow_cap = shadow_cap; wb.vis_words = vis_words;
+    WfBuffers wbs[kWfStreams];
+    for (int s = 0; s < n_streams; s++) {
+        char* base = static_cast<char*>(ctx->wf_blob) + per_stream * (size_t)s;
+        WfBuffers& wb = wbs[s];
+        wb.ray = reinterpret_cast<double*>(base + o_ray); wb.thr = reinterpret_cast<double*>(base + o_thr);
+        wb.hit = reinterpret_cast<double*>(base + o_hit); wb.result = reinterpret_cast<double*>(base + o_res);
+        wb.hit_tri = reinterpret_cast<int32_t*>(base + o_tri); wb.ctr = reinterpret_cast<uint32_t*>(base + o_ctr);
+        wb.counts = reinterpret_cast<uint32_t*>(base + o_cnt);
+        wb.queue[0] = reinterpret_cast<uint32_t*>(base + o_q0); wb.queue[1] = reinterpret_cast<uint32_t*>(base + o_q1);
+        wb.conn_queue = reinterpret_cast<uint32_t*>(base + o_cq);
+        wb.vtx = reinterpret_cast<double*>(base + o_vtx); wb.vis = reinterpret_cast<unsigned long long*>(base + o_vis);
+        wb.shadow = reinterpret_cast<double*>(base + o_sh); wb.counters = reinterpret_cast<uint32_t*>(base + o_counters);
+        wb.ns = ns; wb.shadow_cap = shadow_cap; wb.vis_words = vis_words;
+    }
 
     WfLaunchCfg cfg;
-    if ((int)scene->host.tree_depth > kWideStackDepth || (int)scene->host.sah_depth > kWideStackDepth)
-        return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
-    // per traversal kernel: its own node table + its own triangle order
-    {
+    {   // per traversal kernel: its own node table + its own triangle order
         const size_t shadow_bytes = (size_t)scene->dev.n_wnodes * sizeof(GpuWideNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
         const size_t extend_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuSahNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
         cfg.lds_bytes = shadow_bytes > extend_bytes ? shadow_bytes : extend_bytes;
@@ -219,24 +237,25 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
 
     const GpuCamera gcam = to_gpu_camera(*cam);
     unsigned long long* stats = stats_mode ? ctx->stats : nullptr;
-    uint32_t* C = wb.counters;
-    auto eye_count = [&](int k) { return C + 8 + 2 * k; };
-    auto eye_cursor = [&](int k) { return C + 8 + 2 * k + 1; };
-    auto light_count = [&](int k) { return C + 8 + 2 * depth + 2 * k; };
-    auto light_cursor = [&](int k) { return C + 8 + 2 * depth + 2 * k + 1; };
-    auto shadow_count = [&](int a) { return C + 8 + 4 * depth + 2 * a; };
-    auto shadow_cursor = [&](int a) { return C + 8 + 4 * depth + 2 * a + 1; };
-    uint32_t* conn_count = C;
 
-    auto queue_empty = [&](const uint32_t* count_ptr, bool& empty) -> int {
-        uint32_t v = 0;
-        HIP_TRY(hipMemcpyAsync(&v, count_ptr, sizeof v, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        empty = (v == 0);
-        return BDPT_OK;
-    };
+    // the internal streams start after everything already queued on the caller's stream ...
+    HIP_TRY(hipEventRecord(ctx->wf_fork, stream));
+    for (int s = 0; s < n_streams; s++) HIP_TRY(hipStreamWaitEvent(ctx->wf_streams[s], ctx->wf_fork, 0));
 
-    for (int64_t first = 0; first < n_owned; first += pixels_per_batch) {
+    int64_t batch = 0;
+    for (int64_t first = 0; first < n_owned; first += pixels_per_batch, batch++) {
+        const int si = (int)(batch % n_streams);
+        hipStream_t st = ctx->wf_streams[si];
+        const WfBuffers& wb = wbs[si];
+        uint32_t* C = wb.counters;
+        auto eye_count = [&](int k) { return C + 8 + 2 * k; };
+        auto eye_cursor = [&](int k) { return C + 8 + 2 * k + 1; };
+        auto light_count = [&](int k) { return C + 8 + 2 * depth + 2 * k; };
+        auto light_cursor = [&](int k) { return C + 8 + 2 * depth + 2 * k + 1; };
+        auto shadow_count = [&](int a) { return C + 8 + 4 * depth + 2 * a; };
+        auto shadow_cursor = [&](int a) { return C + 8 + 4 * depth + 2 * a + 1; };
+        uint32_t* conn_count = C;
+
         WfBatch b;
         b.seed = seed;
         b.rows = ctx->rows;
@@ -247,55 +266,43 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         b.n_owned = n_owned;
         const uint32_t n_slots = (uint32_t)((int64_t)b.n_pixels * spp);
 
-        HIP_TRY(hipMemsetAsync(C, 0, n_counters * 4, stream));
-        HIP_TRY(wf_gen_eye(scene->dev, gcam, wb, b, cfg, stream));
+        HIP_TRY(hipMemsetAsync(C, 0, n_counters * 4, st));
+        HIP_TRY(wf_gen_eye(scene->dev, gcam, wb, b, cfg, st));
         // eye subpath: camera.h:303 -> trace_path(r, depth, ...)
         int cur = 0;
         for (int k = 0; k < depth; k++) {
             const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
             const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
-            HIP_TRY(wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, stream));
+            HIP_TRY(wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st));
             const int nxt = (k == 0) ? 0 : (cur ^ 1);
             HIP_TRY(wf_shade(scene->dev, gcam, wb, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, cfg,
-                             stats, stream));
+                             stats, st));
             cur = nxt;
-            if (k >= 3 && (k & 3) == 3 && k < depth - 1) {
-                bool empty = false;
-                int rc = queue_empty(eye_count(k), empty);
-                if (rc != BDPT_OK) return rc;
-                if (empty) break;
-            }
         }
         // light subpath: camera.h:313 -> build_light_path -> trace_path(light_ray, depth - 1, ...)
         if (depth > 0) {
-            HIP_TRY(wf_gen_light(scene->dev, gcam, wb, b, wb.queue[0], light_count(0), cfg, stats, stream));
+            HIP_TRY(wf_gen_light(scene->dev, gcam, wb, b, wb.queue[0], light_count(0), cfg, stats, st));
             cur = 0;
             for (int k = 0; k < depth - 1; k++) {
-                HIP_TRY(wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, stream));
+                HIP_TRY(wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st));
                 HIP_TRY(wf_shade(scene->dev, gcam, wb, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
-                                 light_count(k + 1), k == depth - 2, cfg, stats, stream));
+                                 light_count(k + 1), k == depth - 2, cfg, stats, st));
                 cur ^= 1;
-                if (k >= 3 && (k & 3) == 3 && k < depth - 2) {
-                    bool empty = false;
-                    int rc = queue_empty(light_count(k + 1), empty);
-                    if (rc != BDPT_OK) return rc;
-                    if (empty) break;
-                }
             }
         }
         // connections: camera.h:316-320
-        HIP_TRY(wf_conn_prepare(gcam, wb, b, conn_count, cfg, stats, stream));
-        bool no_connections = false;
-        if (depth > 0) {
-            int rc = queue_empty(conn_count, no_connections);
-            if (rc != BDPT_OK) return rc;
+        HIP_TRY(wf_conn_prepare(gcam, wb, b, conn_count, cfg, stats, st));
+        for (int a = 0; a < depth; a++) {
+            HIP_TRY(wf_conn_gen(scene->dev, gcam, wb, a, conn_count, shadow_count(a), cfg, stats, st));
+            HIP_TRY(wf_occlude(scene->dev, wb, shadow_count(a), shadow_cursor(a), cfg, stats, st));
+            HIP_TRY(wf_conn_accum(scene->dev, gcam, wb, a, conn_count, cfg, st));
         }
-        for (int a = 0; a < depth && !no_connections; a++) {
-            HIP_TRY(wf_conn_gen(scene->dev, gcam, wb, a, conn_count, shadow_count(a), cfg, stats, stream));
-            HIP_TRY(wf_occlude(scene->dev, wb, shadow_count(a), shadow_cursor(a), cfg, stats, stream));
-            HIP_TRY(wf_conn_accum(scene->dev, gcam, wb, a, conn_count, cfg, stream));
-        }
-        HIP_TRY(wf_resolve(gcam, wb, b, d_fb, cfg, stream));
+        HIP_TRY(wf_resolve(gcam, wb, b, d_fb, cfg, st));
+    }
+    // ... and the caller's stream continues after all of them
+    for (int s = 0; s < n_streams; s++) {
+        HIP_TRY(hipEventRecord(ctx->wf_join[s], ctx->wf_streams[s]));
+        HIP_TRY(hipStreamWaitEvent(stream, ctx->wf_join[s], 0));
     }
     return BDPT_OK;
 }
@@ -371,9 +378,17 @@ int bdpt_context_create(int device_index, bdpt_context** out) {
     ctx->device = device_index;
     ctx->cu_count = prop.multiProcessorCount;
     if (hipMalloc(&ctx->unit_counter, 256) != hipSuccess || hipMalloc(&ctx->stats, 256) != hipSuccess ||
-        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming) != hipSuccess) {
         bdpt_context_destroy(ctx);
         return fail(BDPT_ERR_OUT_OF_MEMORY, "device allocation failed");
+    }
+    for (int i = 0; i < kWfStreams; i++) {
+        if (hipStreamCreateWithFlags(&ctx->wf_streams[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->wf_join[i], hipEventDisableTiming) != hipSuccess) {
+            bdpt_context_destroy(ctx);
+            return fail(BDPT_ERR_DEVICE, "stream creation failed");
+        }
     }
     *out = ctx;
     return BDPT_OK;
@@ -388,6 +403,11 @@ int bdpt_context_destroy(bdpt_context* ctx) {
     if (ctx->unit_counter) (void)hipFree(ctx->unit_counter);
     if (ctx->stats) (void)hipFree(ctx->stats);
     if (ctx->wf_blob) (void)hipFree(ctx->wf_blob);
+    for (int i = 0; i < kWfStreams; i++) {
+        if (ctx->wf_streams[i]) (void)hipStreamDestroy(ctx->wf_streams[i]);
+        if (ctx->wf_join[i]) (void)hipEventDestroy(ctx->wf_join[i]);
+    }
+    if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;

@@ -40,12 +40,16 @@ BDPT_DEV void flush_wave_counter(unsigned long long* dst, unsigned long long x) 
 
 // pixel (i, j) and stratum (s_i, s_j) of a slot; false for slots past the end of the batch / image
 BDPT_DEV bool slot_to_sample(const GpuCamera& cam, const WfBatch& b, uint32_t slot, int& i, int& j, int& s) {
-    const int p = (int)(slot % (uint32_t)b.pixels_stride);
-    s = (int)(slot / (uint32_t)b.pixels_stride);
-    const long long q = b.first_pixel + p;
-    if (p >= b.n_pixels || q >= b.n_owned) return false;
-    j = b.rows[q / b.row_w];
-    i = b.x0 + (int)(q % b.row_w);
+    // 32-bit arithmetic throughout (the host guarantees fewer than 2^31 owned pixels): 64-bit integer
+    // division is a long software sequence on the GPU
+    const uint32_t sv = slot / (uint32_t)b.pixels_stride;
+    const uint32_t p = slot - sv * (uint32_t)b.pixels_stride;
+    s = (int)sv;
+    const uint32_t q = (uint32_t)b.first_pixel + p;
+    if (p >= (uint32_t)b.n_pixels || q >= (uint32_t)b.n_owned) return false;
+    const uint32_t row = q / (uint32_t)b.row_w;
+    j = b.rows[row];
+    i = b.x0 + (int)(q - row * (uint32_t)b.row_w);
     return true;
 }
 
@@ -568,13 +572,14 @@ __global__ __launch_bounds__(kBlock) void k_resolve(GpuCamera cam, WfBuffers wb,
     for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n; t += gridDim.x * kBlock) {
         const int ch = (int)(t / (uint32_t)b.n_pixels);
         const int p = (int)(t - (uint32_t)ch * (uint32_t)b.n_pixels);
-        const long long q = b.first_pixel + p;
-        if (q >= b.n_owned) continue;
+        const uint32_t q = (uint32_t)b.first_pixel + (uint32_t)p;
+        if (q >= (uint32_t)b.n_owned) continue;
         const double* src = wb.result + (uint64_t)ch * wb.ns + p;
         double acc = 0.0;
         for (int s = 0; s < spp; s++) acc = acc + src[(uint64_t)s * b.pixels_stride];
-        const int j = b.rows[q / b.row_w];
-        const int i = b.x0 + (int)(q % b.row_w);
+        const uint32_t row = q / (uint32_t)b.row_w;
+        const int j = b.rows[row];
+        const int i = b.x0 + (int)(q - row * (uint32_t)b.row_w);
         fb[((size_t)j * cam.width + i) * 3 + ch] = acc;
     }
 }
