@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -38,8 +39,14 @@ int hip_fail(hipError_t e, const char* what) {
 
 constexpr int kBlock = 256;
 constexpr int kStatWords = 11;
-constexpr int kWfStreams = 4;                               // batches in flight (one HIP stream each)
+constexpr int kWfStreams = 8;                               // most batches in flight (one HIP stream each)
 constexpr size_t kWfWorkspaceBudget = (size_t)48 << 30;     // bytes of wavefront state for all of them
+
+// tuning knobs, overridable from the environment for experiments
+int env_int(const char* name, int fallback) {
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : fallback;
+}
 
 }  // namespace
 
@@ -177,18 +184,21 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const size_t per_slot = sizeof(double) * (6 + 3 + 3 + 3) + sizeof(uint32_t) * 6 + vslots * 10 * sizeof(double) +
                             vis_words * sizeof(unsigned long long) + shadow_per_slot * 8 * sizeof(double);
     const size_t budget = (size_t)kWfWorkspaceBudget;           // for all batches in flight, of 288 GB
-    int64_t ns_target = (int64_t)(budget / kWfStreams / per_slot);
-    if (ns_target > ((int64_t)1 << 22)) ns_target = (int64_t)1 << 22;
+    int want_streams = env_int("BDPT_WF_STREAMS", 4);
+    want_streams = want_streams < 1 ? 1 : (want_streams > kWfStreams ? kWfStreams : want_streams);
+    int64_t ns_target = (int64_t)(budget / want_streams / per_slot);
+    const int64_t ns_cap = (int64_t)1 << env_int("BDPT_WF_BATCH_LOG2", 22);
+    if (ns_target > ns_cap) ns_target = ns_cap;
     if (spp > ns_target) return fail(BDPT_ERR_UNSUPPORTED, "samples per pixel exceed the wavefront batch capacity");
     int64_t pixels_per_batch = ns_target / spp;
     // small renders: still split over the streams so that the tails overlap
-    const int64_t even_share = (n_owned + kWfStreams - 1) / kWfStreams;
+    const int64_t even_share = (n_owned + want_streams - 1) / want_streams;
     if (pixels_per_batch > even_share) pixels_per_batch = even_share > 0 ? even_share : 1;
     const uint64_t ns = (uint64_t)(pixels_per_batch * spp);
     const uint64_t shadow_cap = ns * shadow_per_slot;
     const size_t n_counters = 8 + 6 * (size_t)(depth > 0 ? depth : 1);
     const int64_t n_batches = (n_owned + pixels_per_batch - 1) / pixels_per_batch;
-    const int n_streams = (int)(n_batches < kWfStreams ? n_batches : kWfStreams);
+    const int n_streams = (int)(n_batches < want_streams ? n_batches : want_streams);
 
     // carve one workspace per stream
     size_t off = 0;
@@ -232,7 +242,11 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     if (!cfg.lds_scene) cfg.lds_bytes = 0;
     int per_cu = 1;
     HIP_TRY(wf_persistent_blocks_per_cu(cfg.lds_scene, cfg.lds_bytes, &per_cu));
+    if (!cfg.lds_scene && per_cu > 3) per_cu = 3;   // measured: more resident waves only thrash L1 on large scenes
+    per_cu = env_int("BDPT_WF_BLOCKS_PER_CU", per_cu);
     cfg.persistent_blocks = ctx->cu_count * per_cu;
+    cfg.refill_threshold = env_int("BDPT_WF_REFILL", 16);
+    cfg.chunk = (uint32_t)env_int("BDPT_WF_CHUNK", 128);
     cfg.stream_blocks = ctx->cu_count * 8;
 
     const GpuCamera gcam = to_gpu_camera(*cam);

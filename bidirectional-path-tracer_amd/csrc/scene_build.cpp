@@ -215,6 +215,36 @@ struct SahBuilder {
     }
 };
 
+// Puts the `top` records nearest the root first (breadth-first), the rest in their previous order,
+// and rewrites the interior child references.  The traversal kernels keep that prefix in LDS.
+template <class NodeT>
+void hoist_top_levels(std::vector<NodeT>& nodes, size_t top) {
+    const size_t n = nodes.size();
+    if (n <= 2 || top <= 1) return;
+    std::vector<int32_t> order;
+    order.reserve(n);
+    std::vector<char> taken(n, 0);
+    order.push_back(0);
+    taken[0] = 1;
+    for (size_t head = 0; head < order.size() && order.size() < top; head++) {
+        const NodeT& nd = nodes[order[head]];
+        const int32_t kids[2] = {nd.child0, nd.child1};
+        for (int32_t c : kids)
+            if (c >= 0 && !taken[c] && order.size() < top) { order.push_back(c); taken[c] = 1; }
+    }
+    for (size_t i = 0; i < n; i++) if (!taken[i]) order.push_back((int32_t)i);
+    std::vector<int32_t> new_index(n);
+    for (size_t k = 0; k < n; k++) new_index[order[k]] = (int32_t)k;
+    std::vector<NodeT> out(n);
+    for (size_t k = 0; k < n; k++) {
+        NodeT nd = nodes[order[k]];
+        if (nd.child0 >= 0) nd.child0 = new_index[nd.child0];
+        if (nd.child1 >= 0) nd.child1 = new_index[nd.child1];
+        out[k] = nd;
+    }
+    nodes.swap(out);
+}
+
 }  // namespace
 
 std::string build_host_scene(const double* tv, const int32_t* tri_material, uint32_t n_tri,
@@ -355,6 +385,8 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
         }
     }
 
+    hoist_top_levels(out.wnodes, kLdsTopWideNodes);
+
     // closest-hit hierarchy over the same triangles (referenced by their position in `stris`)
     {
         SahBuilder sb;
@@ -387,6 +419,7 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
             w.child1 = ~(int32_t)0;
             sb.nodes.push_back(w);
         }
+        hoist_top_levels(sb.nodes, kLdsTopSahNodes);
         out.xnodes = sb.nodes;
         out.sah_depth = sb.max_depth;
         out.xtris.resize(sb.leaf_order.size());

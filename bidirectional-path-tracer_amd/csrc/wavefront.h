@@ -52,6 +52,8 @@ struct WfLaunchCfg {
     int stream_blocks;        // grid of the grid-stride kernels
     bool lds_scene;
     size_t lds_bytes;
+    int refill_threshold;     // a wave fetches new rays when at least this many of its lanes are idle
+    uint32_t chunk;           // ray indices a wave takes from the global cursor at a time
 };
 
 // counts of the work done, accumulated by the kernels when `stats` is non-null (bdpt_stats order)

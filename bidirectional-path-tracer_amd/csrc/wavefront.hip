@@ -13,23 +13,30 @@ namespace bdpt {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kRefillThreshold = 16;   // refill when at least this many lanes of a wave are idle
-constexpr uint32_t kChunk = 256;       // ray indices a wave takes from the global cursor at a time
 
 BDPT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
 BDPT_DEV uint32_t rank_in_mask(unsigned long long mask) {
     return __builtin_popcountll(mask & ((1ull << lane_id()) - 1ull));
 }
 
-// append `flag`-ged lanes' values to a queue: one atomic per wave
-BDPT_DEV void wave_append(bool flag, uint32_t value, uint32_t* queue, uint32_t* count) {
-    unsigned long long m = __ballot(flag);
-    if (m == 0) return;
-    uint32_t base = 0;
-    const int leader = __builtin_ctzll(m);
-    if ((int)lane_id() == leader) base = atomicAdd(count, (uint32_t)__builtin_popcountll(m));
-    base = __shfl(base, leader, 64);
-    if (flag) queue[base + rank_in_mask(m)] = value;
+// append with ONE atomic per workgroup: every wave contributes its count through LDS.  All threads of
+// the workgroup must call it together.  (A single queue counter saturates at under 100 atomics per
+// microsecond, so a queue fed by one atomic per wave costs ~0.7 ms per 4 M entries.)
+constexpr int kStageBlock = 1024;
+BDPT_DEV void block_append(bool flag, uint32_t value, uint32_t* queue, uint32_t* count, uint32_t* s_wave, uint32_t* s_base) {
+    const unsigned long long m = __ballot(flag);
+    const uint32_t wave = threadIdx.x >> 6;
+    if (lane_id() == 0) s_wave[wave] = (uint32_t)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        const uint32_t n_waves = blockDim.x >> 6;
+        for (uint32_t w = 0; w < n_waves; w++) { const uint32_t t = s_wave[w]; s_wave[w] = run; run += t; }
+        *s_base = run ? atomicAdd(count, run) : 0u;
+    }
+    __syncthreads();
+    if (flag) queue[*s_base + s_wave[wave] + rank_in_mask(m)] = value;
+    __syncthreads();
 }
 
 BDPT_DEV void flush_wave_counter(unsigned long long* dst, unsigned long long x) {
@@ -115,6 +122,7 @@ __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb,
 //  * the root's own box (bvh.h:52 at the root) is not tested separately: it contains both child
 //    boxes, and the slab arithmetic is monotone, so a ray that passes a child box passes the root box.
 constexpr int kStackDepth = kWideStackDepth;
+constexpr size_t kTopLdsBytes = 32 * 1024;   // = kLdsTopSahNodes * 64 = kLdsTopWideNodes * 128
 constexpr int32_t kPop = (int32_t)0x80000000;   // neither an interior index (>= 0) nor a leaf reference
 
 template <class NodeT>
@@ -122,6 +130,20 @@ struct TreeMem {
     const NodeT* wn;          // global or LDS copy
     const GpuTri* st;
     BDPT_DEV NodeT wnode(int32_t i) const { return wn[i]; }
+    BDPT_DEV GpuTri stri(uint32_t i) const { return st[i]; }
+};
+
+// Large scenes: the records nearest the root come from LDS, the deeper ones from global memory.
+template <class NodeT>
+struct TopLdsMem {
+    const NodeT* lds;         // first n_lds records
+    const NodeT* wn;
+    const GpuTri* st;
+    int32_t n_lds;
+    BDPT_DEV NodeT wnode(int32_t i) const {
+        if (i < n_lds) return lds[i];
+        return wn[i];
+    }
     BDPT_DEV GpuTri stri(uint32_t i) const { return st[i]; }
 };
 
@@ -151,7 +173,7 @@ BDPT_DEV void slab(const T* blo, const T* bhi, V3 o, double ix, double iy, doubl
 // pair's visibility bit.
 template <bool SHADOW, bool STATS, class Mem>
 BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffers& wb, const uint32_t* queue, uint32_t count,
-                             uint32_t* cursor, unsigned long long* stats) {
+                             uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk) {
     bool has = false;
     uint32_t slot = 0;
     int32_t cur = kPop;
@@ -312,7 +334,7 @@ BDPT_DEV void stage_tree(const NodeT* nodes, uint32_t n_nodes, const GpuTri* tri
 template <bool SHADOW, bool STATS, bool LDS_SCENE>
 __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
                                                      const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
-                                                     unsigned long long* stats) {
+                                                     unsigned long long* stats, int refill_threshold, uint32_t chunk) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
     if (SHADOW) {
@@ -321,10 +343,13 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
             GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_wnodes);
             stage_tree(sc.wnodes, sc.n_wnodes, sc.stris, sc.n_tris, l_nodes, l_tris);
             TreeMem<GpuWideNode> mem{l_nodes, l_tris};
-            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats);
+            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, chunk);
         } else {
-            TreeMem<GpuWideNode> mem{sc.wnodes, sc.stris};
-            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats);
+            GpuWideNode* l_nodes = reinterpret_cast<GpuWideNode*>(smem);
+            const uint32_t n_top = sc.n_wnodes < kLdsTopWideNodes ? sc.n_wnodes : kLdsTopWideNodes;
+            stage_tree(sc.wnodes, n_top, sc.stris, 0u, l_nodes, (GpuTri*)nullptr);
+            TopLdsMem<GpuWideNode> mem{l_nodes, sc.wnodes, sc.stris, (int32_t)n_top};
+            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, chunk);
         }
     } else {
         if (LDS_SCENE) {
@@ -332,26 +357,31 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
             GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
             stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
             TreeMem<GpuSahNode> mem{l_nodes, l_tris};
-            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats);
+            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, chunk);
         } else {
-            TreeMem<GpuSahNode> mem{sc.xnodes, sc.xtris};
-            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats);
+            GpuSahNode* l_nodes = reinterpret_cast<GpuSahNode*>(smem);
+            const uint32_t n_top = sc.n_xnodes < kLdsTopSahNodes ? sc.n_xnodes : kLdsTopSahNodes;
+            stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
+            TopLdsMem<GpuSahNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
+            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, chunk);
         }
     }
 }
 
 // ------------------------------------------------------------------ shading of one bounce
 template <bool EYE, bool STATS>
-__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
+__global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
                                                   const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
                                                   uint32_t* count_out, int last_bounce, unsigned long long* stats) {
+    __shared__ uint32_t s_wave[kStageBlock / 64];
+    __shared__ uint32_t s_base;
     const uint32_t count = count_in_ptr ? *count_in_ptr : count_in_imm;
     const uint64_t ns = wb.ns;
     const int depth = cam.max_depth;
     uint32_t n_stored = 0;
-    // whole waves iterate together so that the ballot-based append sees every lane
-    const uint32_t rounded = (count + 63u) & ~63u;
-    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < rounded; k += gridDim.x * kBlock) {
+    // whole workgroups iterate together so that the append sees every thread
+    const uint32_t rounded = (count + (kStageBlock - 1)) & ~(uint32_t)(kStageBlock - 1);
+    for (uint32_t k = blockIdx.x * kStageBlock + threadIdx.x; k < rounded; k += gridDim.x * kStageBlock) {
         bool cont = false;
         uint32_t slot = 0;
         if (k < count) {
@@ -396,22 +426,24 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, GpuCamera cam, Wf
                 }
             }
         }
-        wave_append(cont, slot, queue_out, count_out);
+        block_append(cont, slot, queue_out, count_out, s_wave, &s_base);
     }
     if (STATS) flush_wave_counter(&stats[10], n_stored);
 }
 
 // ------------------------------------------------------------------ light subpath start
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_gen_light(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, uint32_t* queue_out,
+__global__ __launch_bounds__(kStageBlock) void k_gen_light(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, uint32_t* queue_out,
                                                       uint32_t* count_out, unsigned long long* stats) {
     const uint32_t spp = (uint32_t)(cam.sqrt_spp * cam.sqrt_spp);
     const uint32_t n = (uint32_t)b.pixels_stride * spp;
     const uint64_t ns = wb.ns;
     const int depth = cam.max_depth;
-    const uint32_t rounded = (n + 63u) & ~63u;
+    __shared__ uint32_t s_wave[kStageBlock / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t rounded = (n + (kStageBlock - 1)) & ~(uint32_t)(kStageBlock - 1);
     uint32_t n_stored = 0;
-    for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < rounded; slot += gridDim.x * kBlock) {
+    for (uint32_t slot = blockIdx.x * kStageBlock + threadIdx.x; slot < rounded; slot += gridDim.x * kStageBlock) {
         bool cont = false;
         int pi, pj, ps;
         if (slot < n && slot_to_sample(cam, b, slot, pi, pj, ps)) {
@@ -431,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void k_gen_light(SceneDev sc, GpuCamera cam
                 }
             }
         }
-        wave_append(cont, slot, queue_out, count_out);
+        block_append(cont, slot, queue_out, count_out, s_wave, &s_base);
     }
     if (STATS) flush_wave_counter(&stats[10], n_stored);
 }
@@ -439,14 +471,16 @@ __global__ __launch_bounds__(kBlock) void k_gen_light(SceneDev sc, GpuCamera cam
 // ------------------------------------------------------------------ connections
 // samples that have a light path and at least one stored vertex on both sides
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_conn_prepare(GpuCamera cam, WfBuffers wb, WfBatch b, uint32_t* conn_count,
+__global__ __launch_bounds__(kStageBlock) void k_conn_prepare(GpuCamera cam, WfBuffers wb, WfBatch b, uint32_t* conn_count,
                                                          unsigned long long* stats) {
     const uint32_t spp = (uint32_t)(cam.sqrt_spp * cam.sqrt_spp);
     const uint32_t n = (uint32_t)b.pixels_stride * spp;
     const uint64_t ns = wb.ns;
-    const uint32_t rounded = (n + 63u) & ~63u;
+    __shared__ uint32_t s_wave[kStageBlock / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t rounded = (n + (kStageBlock - 1)) & ~(uint32_t)(kStageBlock - 1);
     unsigned long long draws = 0, samples = 0;
-    for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < rounded; slot += gridDim.x * kBlock) {
+    for (uint32_t slot = blockIdx.x * kStageBlock + threadIdx.x; slot < rounded; slot += gridDim.x * kStageBlock) {
         bool want = false;
         int pi, pj, ps;
         if (slot < n && slot_to_sample(cam, b, slot, pi, pj, ps)) {
@@ -463,7 +497,7 @@ __global__ __launch_bounds__(kBlock) void k_conn_prepare(GpuCamera cam, WfBuffer
                 want = (cnt & 0xFFFu) > 0 && ((cnt >> 12) & 0xFFFu) > 0;
             }
         }
-        wave_append(want, slot, wb.conn_queue, conn_count);
+        block_append(want, slot, wb.conn_queue, conn_count, s_wave, &s_base);
     }
     if (STATS) { flush_wave_counter(&stats[8], draws); flush_wave_counter(&stats[9], samples); }
 }
@@ -590,7 +624,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(GpuCamera cam, WfBuffers wb,
 hipError_t wf_persistent_blocks_per_cu(bool lds_scene, size_t lds_bytes, int* out) {
     int n = 0;
     hipError_t e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<false, false, true>, kBlock, lds_bytes)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<false, false, false>, kBlock, 0);
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<false, false, false>, kBlock, kTopLdsBytes);
     *out = n < 1 ? 1 : n;
     return e;
 }
@@ -606,13 +640,13 @@ static hipError_t launch_traverse(const SceneDev& sc, const WfBuffers& wb, const
                                   uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
                                   hipStream_t st) {
     dim3 grid(cfg.persistent_blocks), block(kBlock);
-    const size_t shm = cfg.lds_scene ? cfg.lds_bytes : 0;
+    const size_t shm = cfg.lds_scene ? cfg.lds_bytes : kTopLdsBytes;
     if (stats) {
-        if (cfg.lds_scene) hipLaunchKernelGGL((k_traverse<SHADOW, true, true>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats);
-        else hipLaunchKernelGGL((k_traverse<SHADOW, true, false>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats);
+        if (cfg.lds_scene) hipLaunchKernelGGL((k_traverse<SHADOW, true, true>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk);
+        else hipLaunchKernelGGL((k_traverse<SHADOW, true, false>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk);
     } else {
-        if (cfg.lds_scene) hipLaunchKernelGGL((k_traverse<SHADOW, false, true>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats);
-        else hipLaunchKernelGGL((k_traverse<SHADOW, false, false>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats);
+        if (cfg.lds_scene) hipLaunchKernelGGL((k_traverse<SHADOW, false, true>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk);
+        else hipLaunchKernelGGL((k_traverse<SHADOW, false, false>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk);
     }
     return hipGetLastError();
 }
@@ -630,7 +664,7 @@ hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* s
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
                     const uint32_t* queue_in, const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
                     uint32_t* count_out, bool last_bounce, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    dim3 grid(cfg.stream_blocks), block(kBlock);
+    dim3 grid(cfg.stream_blocks / 4), block(kStageBlock);
     const int last = last_bounce ? 1 : 0;
     if (eye) {
         if (stats) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, stats);
@@ -644,7 +678,7 @@ hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& w
 
 hipError_t wf_gen_light(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* queue_out,
                         uint32_t* count_out, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    dim3 grid(cfg.stream_blocks), block(kBlock);
+    dim3 grid(cfg.stream_blocks / 4), block(kStageBlock);
     if (stats) hipLaunchKernelGGL((k_gen_light<true>), grid, block, 0, st, sc, cam, wb, b, queue_out, count_out, stats);
     else hipLaunchKernelGGL((k_gen_light<false>), grid, block, 0, st, sc, cam, wb, b, queue_out, count_out, stats);
     return hipGetLastError();
@@ -652,7 +686,7 @@ hipError_t wf_gen_light(const SceneDev& sc, const GpuCamera& cam, const WfBuffer
 
 hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* conn_count,
                            const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    dim3 grid(cfg.stream_blocks), block(kBlock);
+    dim3 grid(cfg.stream_blocks / 4), block(kStageBlock);
     if (stats) hipLaunchKernelGGL((k_conn_prepare<true>), grid, block, 0, st, cam, wb, b, conn_count, stats);
     else hipLaunchKernelGGL((k_conn_prepare<false>), grid, block, 0, st, cam, wb, b, conn_count, stats);
     return hipGetLastError();
