@@ -34,8 +34,13 @@ PKG = "bidirectional-path-tracer_amd"
 
 HBM_PEAK_GBS = 8000.0
 
-# FP64 record sizes of the device layout (bytes), see DESIGN.md "Algorithmic bytes"
-B_RAY, B_NODE, B_TRI, B_VERTEX, B_PIXEL = 96, 64, 80, 80, 24
+# Algorithmic bytes (FP64 records of the device layout), see DESIGN.md "Algorithmic bytes":
+#   closest-hit ray : origin + direction 48, queue index 4, triangle id 4, (t, u, v) 24
+#   visibility ray  : origin + direction + max_t + tag 64, visibility word 8
+#   node record     : counted by the kernels in units of 64 bytes; triangle 80; stored path vertex 80
+#   per ray outside traversal (shading): ray + hit 76 in, next ray + throughput 72 out
+#   per connection pair: both vertices read when its ray is generated and when it is accumulated
+B_RAY_CLOSEST, B_RAY_SHADOW, B_NODE, B_TRI, B_VERTEX, B_PIXEL, B_RAY_STATE = 80, 72, 64, 80, 80, 24, 148
 
 WORKLOADS = {
     # name: (builder, kwargs, description)
@@ -227,14 +232,16 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_roofline:
-        # untimed counting pass over every 8th row (same kernel with its work counters on)
+        # untimed counting pass over every 8th row (same kernels with their work counters on)
         fb2 = torch.zeros_like(fb)
         scene.render_device(cam, fb2.data_ptr(), seed=args.seed, shard=(0, 8, 1), want_stats="work", stream=stream,
                             megakernel=args.megakernel)
         st = scene.last_stats()
         frac = st.samples / float(W * H * spp_used)
-        alg = (B_RAY * (st.rays_traced + st.shadow_rays) + B_NODE * st.bvh_node_visits + B_TRI * st.triangle_tests +
-               B_VERTEX * (st.path_vertices + 2 * st.connection_pairs) + B_PIXEL * (st.samples / spp_used)) / frac
+        alg_traverse = (B_RAY_CLOSEST * st.rays_traced + B_RAY_SHADOW * st.shadow_rays + B_NODE * st.bvh_node_visits +
+                        B_TRI * st.triangle_tests) / frac
+        alg = alg_traverse + (B_RAY_STATE * st.rays_traced + B_VERTEX * (st.path_vertices + 4 * st.connection_pairs) +
+                              B_PIXEL * (st.samples / spp_used)) / frac
         ms = sum(kernel_ms) / len(kernel_ms)
         achieved = alg / (ms * 1e-3) / 1e9
         traffic = None
@@ -242,19 +249,40 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(args.workload, {}).get("hbm_bytes_per_launch")
+                traffic = tj.get(args.workload + ("/megakernel" if args.megakernel else ""), {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "kernel": "render_kernel (single persistent kernel)" if args.megakernel else "wavefront pipeline (all kernels of one frame)",
+            "kernel": "render_kernel (single persistent kernel)" if args.megakernel else
+                      "one bdpt_render_device call = all kernels of one frame (4 batches in flight on internal streams), "
+                      "HIP events on the caller's stream",
             "kernel_ms": ms, "algorithmic_bytes_per_launch": alg,
             "per_sample": {"trace_rays": st.rays_traced / st.samples, "shadow_rays": st.shadow_rays / st.samples,
                            "box_tests": st.aabb_tests / st.samples, "node_records_64B": st.bvh_node_visits / st.samples, "triangle_tests": st.triangle_tests / st.samples,
                            "connection_pairs": st.connection_pairs / st.samples, "rng_draws": st.rng_draws / st.samples},
             "rays_per_s": (st.rays_traced + st.shadow_rays) / frac / (ms * 1e-3),
         }
+        if not args.megakernel:
+            # one more untimed frame with a HIP event pair around every traversal launch (on the launch's own stream)
+            scene.render_device(cam, fb2.data_ptr(), seed=args.seed, stream=stream, time_stages=True)
+            ms0, n0 = scene.last_stage_ms(0)
+            ms1, n1 = scene.last_stage_ms(1)
+            n_launch = max(1, n0 + n1)
+            avg_ms = (ms0 + ms1) / n_launch
+            dom = alg_traverse / n_launch / (avg_ms * 1e-3) / 1e9
+            out["roofline"]["dominant_kernel"] = {
+                "name": "k_traverse (closest-hit and visibility instantiations)",
+                "launches_per_frame": n_launch, "avg_launch_ms": avg_ms,
+                "closest_hit": {"launches": n0, "avg_launch_ms": ms0 / max(1, n0)},
+                "visibility": {"launches": n1, "avg_launch_ms": ms1 / max(1, n1)},
+                "algorithmic_bytes_per_launch": alg_traverse / n_launch,
+                "achieved": dom, "unit": "GB/s", "frac": dom / HBM_PEAK_GBS,
+                "summed_ms_over_frame_ms": (ms0 + ms1) / ms,
+                "note": "up to 4 launches (one per batch in flight) share the chip, so a launch's own rate is about a "
+                        "quarter of the chip-level rate above",
+            }
     if cpu is not None:
         out["cpu_baseline"] = cpu
 

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libbdpt_amd.so")
 BDPT_RENDER_COUNT_STATS = 1     # counters with the reference's BvhStats semantics
 BDPT_RENDER_COUNT_WORK = 2      # counters of the work the production path does
 BDPT_RENDER_TIME_KERNEL = 4     # HIP events around the render kernels
+BDPT_RENDER_TIME_STAGES = 16    # HIP event pair around every traversal launch
 BDPT_RENDER_MEGAKERNEL = 8      # single persistent kernel instead of the wavefront pipeline
 
 
@@ -70,7 +71,7 @@ EXPORTED_SYMBOLS = [
     "bdpt_last_error", "bdpt_context_create", "bdpt_context_destroy", "bdpt_camera_initialize", "bdpt_scene_create",
     "bdpt_scene_destroy", "bdpt_scene_get_info", "bdpt_scene_dfs_leaves", "bdpt_scene_node_boxes", "bdpt_trace_closest",
     "bdpt_trace_closest_device", "bdpt_visible", "bdpt_render", "bdpt_render_device", "bdpt_render_get_stats",
-    "bdpt_render_get_kernel_ms",
+    "bdpt_render_get_kernel_ms", "bdpt_render_get_stage_ms",
     "bdpt_colors_to_rgb8", "bdpt_colors_to_rgb8_device", "bdpt_device_sincos", "bdpt_device_random_doubles",
     "bdpt_device_arith",
 ]
@@ -111,6 +112,7 @@ def load_library() -> C.CDLL:
     lib.bdpt_render_device.argtypes = [vp, vp, C.POINTER(CameraState), C.POINTER(RenderParams), vp, vp]
     lib.bdpt_render_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.bdpt_render_get_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.bdpt_render_get_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.bdpt_colors_to_rgb8.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.bdpt_colors_to_rgb8_device.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
     lib.bdpt_device_sincos.argtypes = [vp, vp, u64, vp, vp]
@@ -260,9 +262,11 @@ class Scene:
         return out
 
     @staticmethod
-    def _flags(want_stats, time_kernel=False, megakernel=False):
+    def _flags(want_stats, time_kernel=False, megakernel=False, time_stages=False):
         """want_stats: False / True or "reference" (BvhStats semantics) / "work" (production path's own work)"""
         f = BDPT_RENDER_TIME_KERNEL if time_kernel else 0
+        if time_stages:
+            f |= BDPT_RENDER_TIME_STAGES
         if megakernel:
             f |= BDPT_RENDER_MEGAKERNEL
         if want_stats == "work":
@@ -288,14 +292,14 @@ class Scene:
         return (fb, st) if want_stats else fb
 
     def render_device(self, cam_state: CameraState, d_framebuffer: int, seed=0, rect=None, shard=(0, 1, 1),
-                      want_stats=False, stream: int = 0, time_kernel=False, megakernel=False):
+                      want_stats=False, stream: int = 0, time_kernel=False, megakernel=False, time_stages=False):
         """Framebuffer already in device memory (`d_framebuffer` = device pointer, e.g. tensor.data_ptr())."""
         p = RenderParams()
         p.seed = seed
         if rect is not None:
             p.x0, p.y0, p.x1, p.y1 = [int(v) for v in rect]
         p.shard_index, p.shard_count, p.shard_rows = shard
-        p.flags = self._flags(want_stats, time_kernel, megakernel)
+        p.flags = self._flags(want_stats, time_kernel, megakernel, time_stages)
         _check(self.lib.bdpt_render_device(self.ctx.h, self.h, C.byref(cam_state), C.byref(p), C.c_void_p(d_framebuffer),
                                            C.c_void_p(stream)))
 
@@ -303,6 +307,12 @@ class Scene:
         ms = C.c_float()
         _check(self.lib.bdpt_render_get_kernel_ms(self.ctx.h, C.byref(ms)))
         return float(ms.value)
+
+    def last_stage_ms(self, stage: int):
+        """(sum of launch durations in ms, launches) of traversal stage 0 (closest hit) / 1 (visibility)"""
+        ms, n = C.c_double(), C.c_uint64()
+        _check(self.lib.bdpt_render_get_stage_ms(self.ctx.h, stage, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
 
     def last_stats(self) -> Stats:
         st = Stats()

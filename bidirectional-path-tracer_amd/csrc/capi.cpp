@@ -69,6 +69,11 @@ struct bdpt_context {
     hipStream_t wf_streams[kWfStreams] = {};
     hipEvent_t wf_fork = nullptr;
     hipEvent_t wf_join[kWfStreams] = {};
+    // BDPT_RENDER_TIME_STAGES: one event pair per traversal launch of the last render
+    std::vector<hipEvent_t> stage_events;
+    std::vector<int> stage_kind;          // per pair: 0 closest-hit traversal, 1 visibility traversal
+    size_t stage_pairs = 0;
+    bool stage_valid = false;
 };
 
 struct bdpt_scene {
@@ -171,7 +176,7 @@ int render_megakernel(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_cam
 // such a tail the waves of the other batches keep the chip busy.  Nothing in the pipeline waits for
 // the host: kernels whose queue turned out empty return at once.
 int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, uint64_t seed, int x0, int x1,
-                     int64_t n_owned, double* d_fb, int stats_mode, hipStream_t stream) {
+                     int64_t n_owned, double* d_fb, int stats_mode, bool time_stages, hipStream_t stream) {
     const int depth = cam->max_depth;
     const int64_t spp = (int64_t)cam->sqrt_spp * cam->sqrt_spp;
     const size_t vslots = 2 * (size_t)(depth > 0 ? depth : 1);
@@ -252,6 +257,25 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const GpuCamera gcam = to_gpu_camera(*cam);
     unsigned long long* stats = stats_mode ? ctx->stats : nullptr;
 
+    ctx->stage_pairs = 0;
+    ctx->stage_kind.clear();
+    // event pair around one traversal launch on its own stream
+    auto timed = [&](int kind, hipStream_t st, auto&& launch) -> int {
+        if (!time_stages) { HIP_TRY(launch()); return BDPT_OK; }
+        const size_t at = 2 * ctx->stage_pairs;
+        while (ctx->stage_events.size() < at + 2) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreate(&ev));
+            ctx->stage_events.push_back(ev);
+        }
+        HIP_TRY(hipEventRecord(ctx->stage_events[at], st));
+        HIP_TRY(launch());
+        HIP_TRY(hipEventRecord(ctx->stage_events[at + 1], st));
+        ctx->stage_kind.push_back(kind);
+        ctx->stage_pairs++;
+        return BDPT_OK;
+    };
+
     // the internal streams start after everything already queued on the caller's stream ...
     HIP_TRY(hipEventRecord(ctx->wf_fork, stream));
     for (int s = 0; s < n_streams; s++) HIP_TRY(hipStreamWaitEvent(ctx->wf_streams[s], ctx->wf_fork, 0));
@@ -287,7 +311,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         for (int k = 0; k < depth; k++) {
             const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
             const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
-            HIP_TRY(wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st));
+            { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
             const int nxt = (k == 0) ? 0 : (cur ^ 1);
             HIP_TRY(wf_shade(scene->dev, gcam, wb, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, cfg,
                              stats, st));
@@ -298,7 +322,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
             HIP_TRY(wf_gen_light(scene->dev, gcam, wb, b, wb.queue[0], light_count(0), cfg, stats, st));
             cur = 0;
             for (int k = 0; k < depth - 1; k++) {
-                HIP_TRY(wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st));
+                { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
                 HIP_TRY(wf_shade(scene->dev, gcam, wb, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
                                  light_count(k + 1), k == depth - 2, cfg, stats, st));
                 cur ^= 1;
@@ -308,7 +332,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         HIP_TRY(wf_conn_prepare(gcam, wb, b, conn_count, cfg, stats, st));
         for (int a = 0; a < depth; a++) {
             HIP_TRY(wf_conn_gen(scene->dev, gcam, wb, a, conn_count, shadow_count(a), cfg, stats, st));
-            HIP_TRY(wf_occlude(scene->dev, wb, shadow_count(a), shadow_cursor(a), cfg, stats, st));
+            { int rc = timed(1, st, [&] { return wf_occlude(scene->dev, wb, shadow_count(a), shadow_cursor(a), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
             HIP_TRY(wf_conn_accum(scene->dev, gcam, wb, a, conn_count, cfg, st));
         }
         HIP_TRY(wf_resolve(gcam, wb, b, d_fb, cfg, st));
@@ -340,7 +364,9 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     const int stats_mode = (p->flags & BDPT_RENDER_COUNT_STATS) ? 1 : ((p->flags & BDPT_RENDER_COUNT_WORK) ? 2 : 0);
     const bool want_stats = stats_mode != 0;
     const bool want_time = (p->flags & BDPT_RENDER_TIME_KERNEL) != 0;
+    const bool time_stages = (p->flags & BDPT_RENDER_TIME_STAGES) != 0;
     ctx->stats_valid = false;
+    ctx->stage_valid = false;
     if (want_stats) HIP_TRY(hipMemsetAsync(ctx->stats, 0, sizeof(unsigned long long) * kStatWords, stream));
     if (x0 >= x1 || y0 >= y1) { ctx->stats_valid = want_stats; return BDPT_OK; }
 
@@ -362,8 +388,9 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     if (stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL))
         rc = render_megakernel(ctx, scene, cam, p->seed, (int32_t)rows.size(), x0, x1, n_owned, d_fb, stats_mode, stream);
     else
-        rc = render_wavefront(ctx, scene, cam, p->seed, x0, x1, n_owned, d_fb, stats_mode, stream);
+        rc = render_wavefront(ctx, scene, cam, p->seed, x0, x1, n_owned, d_fb, stats_mode, time_stages, stream);
     if (rc != BDPT_OK) return rc;
+    ctx->stage_valid = time_stages && !(stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL));
     if (want_time) { HIP_TRY(hipEventRecord(ctx->ev_stop, stream)); ctx->timing_valid = true; }
     ctx->stats_valid = want_stats;
     return BDPT_OK;
@@ -421,6 +448,7 @@ int bdpt_context_destroy(bdpt_context* ctx) {
         if (ctx->wf_streams[i]) (void)hipStreamDestroy(ctx->wf_streams[i]);
         if (ctx->wf_join[i]) (void)hipEventDestroy(ctx->wf_join[i]);
     }
+    for (hipEvent_t ev : ctx->stage_events) (void)hipEventDestroy(ev);
     if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -631,6 +659,26 @@ int bdpt_render_get_kernel_ms(bdpt_context* ctx, float* out_ms) {
     DeviceGuard guard(ctx->device);
     HIP_TRY(hipEventSynchronize(ctx->ev_stop));
     HIP_TRY(hipEventElapsedTime(out_ms, ctx->ev_start, ctx->ev_stop));
+    return BDPT_OK;
+}
+
+int bdpt_render_get_stage_ms(bdpt_context* ctx, int stage, double* total_ms, uint64_t* launches) {
+    if (!ctx || !total_ms || !launches) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    if (stage < 0 || stage > 1) return fail(BDPT_ERR_INVALID_ARGUMENT, "unknown stage");
+    if (!ctx->stage_valid) return fail(BDPT_ERR_INVALID_ARGUMENT, "the last render did not request BDPT_RENDER_TIME_STAGES");
+    DeviceGuard guard(ctx->device);
+    double sum = 0.0;
+    uint64_t n = 0;
+    for (size_t k = 0; k < ctx->stage_pairs; k++) {
+        if (ctx->stage_kind[k] != stage) continue;
+        HIP_TRY(hipEventSynchronize(ctx->stage_events[2 * k + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->stage_events[2 * k], ctx->stage_events[2 * k + 1]));
+        sum += ms;
+        n++;
+    }
+    *total_ms = sum;
+    *launches = n;
     return BDPT_OK;
 }
 

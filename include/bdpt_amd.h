@@ -102,7 +102,10 @@ typedef struct bdpt_render_params {
                                        stop at the first hit); ignored when BDPT_RENDER_COUNT_STATS is set */
 #define BDPT_RENDER_MEGAKERNEL 8    /* render with the single persistent kernel (one thread per sample) instead of the
                                        wavefront pipeline; same framebuffer bit for bit (BDPT_RENDER_COUNT_STATS implies it) */
-#define BDPT_RENDER_TIME_KERNEL 4   /* bracket the render kernel with HIP events on its stream (bdpt_render_get_kernel_ms) */
+#define BDPT_RENDER_TIME_KERNEL 4   /* bracket the render kernels of the call with HIP events on the caller's stream
+                                       (bdpt_render_get_kernel_ms) */
+#define BDPT_RENDER_TIME_STAGES 16  /* additionally record a HIP event pair around every ray-traversal launch, on the
+                                       internal stream it is launched on (bdpt_render_get_stage_ms); wavefront pipeline only */
 
 /* Work counters.  The first six have the meaning of the reference's BvhStats
  * (src/core/stats.h:8-16); a triangle referenced twice by a one-triangle BVH node is
@@ -189,6 +192,11 @@ int bdpt_render_get_stats(bdpt_context* ctx, bdpt_stats* out);
 /* Device time of the render kernel of the last call that had BDPT_RENDER_TIME_KERNEL set, from HIP
  * events recorded around the launch on the launch's own stream (waits for the kernel). */
 int bdpt_render_get_kernel_ms(bdpt_context* ctx, float* out_ms);
+/* Sum of the launch durations, and number of launches, of one traversal kernel in the last call that had
+ * BDPT_RENDER_TIME_STAGES set: stage 0 = closest-hit traversal (bvh_node::hit under trace_path,
+ * camera.h:334), stage 1 = visibility traversal (camera.h:437).  Launches of different batches overlap on
+ * the device, so the sum exceeds the wall time of the call.  Waits for the kernels. */
+int bdpt_render_get_stage_ms(bdpt_context* ctx, int stage, double* total_ms, uint64_t* launches);
 
 /* colors_to_rgb8(), src/image/wpng.h:14-35: sum/spp -> clamp [0,0.999] -> sqrt -> *256 -> u8.
  * NaN (undefined behaviour in the reference) maps to 0. */

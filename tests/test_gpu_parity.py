@@ -267,3 +267,25 @@ def test_rgb8_on_device_matches_reference(scenes, ctx):
     capi._check(ctx.lib.bdpt_colors_to_rgb8_device(ctx.h, fb.data_ptr(), 48, 48, int(r["spp"][0]), out.data_ptr(), None))
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), r["rgb8"])
+
+
+def test_device_render_timers(scenes, ctx):
+    """HIP-event timers of a device-buffer render: the whole call on the caller's stream, and one event
+    pair per traversal launch; the framebuffer is the one the host-buffer entry point returns."""
+    import torch
+    flat = scenes.cornell_box(40, 16, 5)
+    sc = ctx.scene(flat)
+    cam = capi.camera_initialize(flat.camera)
+    want = sc.render(cam, seed=4)
+    fb = torch.zeros((cam.image_height, cam.image_width, 3), dtype=torch.float64, device="cuda")
+    sc.render_device(cam, fb.data_ptr(), seed=4, time_kernel=True, time_stages=True)
+    assert sc.last_kernel_ms() > 0.0
+    ms0, n0 = sc.last_stage_ms(0)
+    ms1, n1 = sc.last_stage_ms(1)
+    # per batch: depth + (depth - 1) closest-hit launches and depth visibility launches
+    assert n0 > 0 and n0 % (2 * 5 - 1) == 0 and n1 == (n0 // (2 * 5 - 1)) * 5
+    assert ms0 > 0.0 and ms1 >= 0.0
+    assert_bit_equal(fb.cpu().numpy(), want, "device render")
+    sc.render_device(cam, fb.data_ptr(), seed=4)
+    with pytest.raises(capi.BdptError):
+        sc.last_stage_ms(0)
