@@ -64,10 +64,10 @@ struct GpuSahNode {
 };
 static_assert(sizeof(GpuSahNode) == 64, "GpuSahNode must stay 64 bytes");
 
-// Records [0, kLdsTop*) of the two hierarchies are the levels nearest the root (breadth-first); the
-// traversal kernels copy that prefix (32 KiB) into LDS, so only the deeper visits go to L1/L2.
-constexpr uint32_t kLdsTopSahNodes = 512;
-constexpr uint32_t kLdsTopWideNodes = 256;
+// Records [0, kLdsTop*) of the two hierarchies are the levels nearest the root in breadth-first order; the
+// traversal kernels copy a prefix of them (up to 128 KiB) into LDS, so only the deeper visits go to L1/L2.
+constexpr uint32_t kLdsTopSahNodes = 2048;
+constexpr uint32_t kLdsTopWideNodes = 1024;
 
 // Read once per accepted hit / light sample: unit normal and area (triangle.h:26-29).
 struct GpuTriAux {

@@ -245,14 +245,32 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     }
     cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
     if (!cfg.lds_scene) cfg.lds_bytes = 0;
+    cfg.trav_block = env_int("BDPT_WF_TRAV_BLOCK", 256);
+    if (cfg.trav_block != 256 && cfg.trav_block != 512 && cfg.trav_block != 1024) cfg.trav_block = 256;
+    {
+        int kb = env_int("BDPT_WF_LDS_KB", 32);
+        if (kb < 1) kb = 1;
+        if (kb > 128) kb = 128;
+        cfg.top_nodes = (uint32_t)kb * 1024u / (uint32_t)sizeof(GpuSahNode);
+    }
     int per_cu = 1;
-    HIP_TRY(wf_persistent_blocks_per_cu(cfg.lds_scene, cfg.lds_bytes, &per_cu));
-    if (!cfg.lds_scene && per_cu > 3) per_cu = 3;   // measured: more resident waves only thrash L1 on large scenes
+    HIP_TRY(wf_prepare_traverse(cfg, &per_cu));
+    if (!cfg.lds_scene && per_cu * cfg.trav_block > 768) per_cu = 768 / cfg.trav_block > 0 ? 768 / cfg.trav_block : 1;   // measured: more resident waves only thrash L1 on large scenes
     per_cu = env_int("BDPT_WF_BLOCKS_PER_CU", per_cu);
     cfg.persistent_blocks = ctx->cu_count * per_cu;
     cfg.refill_threshold = env_int("BDPT_WF_REFILL", 16);
     cfg.chunk = (uint32_t)env_int("BDPT_WF_CHUNK", 128);
     cfg.stream_blocks = ctx->cu_count * 8;
+    const bool staged = env_int("BDPT_WF_STAGED", 1) != 0;      // one kernel per bounce and stage instead of the fused subpath kernel
+    {
+        int paths_per_cu = 1;
+        cfg.paths_waves = env_int("BDPT_WF_PATHS_WAVES", 4);
+        if (cfg.paths_waves < 2 || cfg.paths_waves > 4) cfg.paths_waves = 4;
+        HIP_TRY(wf_paths_blocks_per_cu(cfg.lds_scene, cfg.lds_bytes, cfg.paths_waves, &paths_per_cu));
+        paths_per_cu = env_int("BDPT_WF_PATHS_BLOCKS_PER_CU", paths_per_cu);
+        cfg.paths_blocks = ctx->cu_count * paths_per_cu;
+        cfg.shade_threshold = env_int("BDPT_WF_SHADE_THRESHOLD", 24);
+    }
 
     const GpuCamera gcam = to_gpu_camera(*cam);
     unsigned long long* stats = stats_mode ? ctx->stats : nullptr;
@@ -305,27 +323,32 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         const uint32_t n_slots = (uint32_t)((int64_t)b.n_pixels * spp);
 
         HIP_TRY(hipMemsetAsync(C, 0, n_counters * 4, st));
-        HIP_TRY(wf_gen_eye(scene->dev, gcam, wb, b, cfg, st));
-        // eye subpath: camera.h:303 -> trace_path(r, depth, ...)
-        int cur = 0;
-        for (int k = 0; k < depth; k++) {
-            const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
-            const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
-            { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
-            const int nxt = (k == 0) ? 0 : (cur ^ 1);
-            HIP_TRY(wf_shade(scene->dev, gcam, wb, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, cfg,
-                             stats, st));
-            cur = nxt;
-        }
-        // light subpath: camera.h:313 -> build_light_path -> trace_path(light_ray, depth - 1, ...)
-        if (depth > 0) {
-            HIP_TRY(wf_gen_light(scene->dev, gcam, wb, b, wb.queue[0], light_count(0), cfg, stats, st));
-            cur = 0;
-            for (int k = 0; k < depth - 1; k++) {
-                { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
-                HIP_TRY(wf_shade(scene->dev, gcam, wb, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
-                                 light_count(k + 1), k == depth - 2, cfg, stats, st));
-                cur ^= 1;
+        if (!staged) {
+            // both subpaths of every sample: camera.h:300-313
+            HIP_TRY(wf_paths(scene->dev, gcam, wb, b, n_slots, eye_cursor(0), cfg, stats, st));
+        } else {
+            HIP_TRY(wf_gen_eye(scene->dev, gcam, wb, b, cfg, st));
+            // eye subpath: camera.h:303 -> trace_path(r, depth, ...)
+            int cur = 0;
+            for (int k = 0; k < depth; k++) {
+                const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
+                const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
+                { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
+                const int nxt = (k == 0) ? 0 : (cur ^ 1);
+                HIP_TRY(wf_shade(scene->dev, gcam, wb, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, cfg,
+                                 stats, st));
+                cur = nxt;
+            }
+            // light subpath: camera.h:313 -> build_light_path -> trace_path(light_ray, depth - 1, ...)
+            if (depth > 0) {
+                HIP_TRY(wf_gen_light(scene->dev, gcam, wb, b, wb.queue[0], light_count(0), cfg, stats, st));
+                cur = 0;
+                for (int k = 0; k < depth - 1; k++) {
+                    { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
+                    HIP_TRY(wf_shade(scene->dev, gcam, wb, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
+                                     light_count(k + 1), k == depth - 2, cfg, stats, st));
+                    cur ^= 1;
+                }
             }
         }
         // connections: camera.h:316-320

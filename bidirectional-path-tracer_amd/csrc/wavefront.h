@@ -54,11 +54,21 @@ struct WfLaunchCfg {
     size_t lds_bytes;
     int refill_threshold;     // a wave fetches new rays when at least this many of its lanes are idle
     uint32_t chunk;           // ray indices a wave takes from the global cursor at a time
+    int trav_block;           // threads per traversal workgroup when the scene does not fit LDS (256, 512 or 1024)
+    uint32_t top_nodes;       // 64-byte records of the top tree levels each such workgroup keeps in LDS
+    int paths_blocks;         // grid of the fused subpath kernel
+    int paths_waves;          // its register budget: waves per SIMD it is compiled for (2, 3 or 4)
+    int shade_threshold;      // its lanes shade together once this many of a wave have a finished ray
 };
 
 // counts of the work done, accumulated by the kernels when `stats` is non-null (bdpt_stats order)
 hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const WfLaunchCfg& cfg,
                       hipStream_t st);
+// eye and light subpath of every sample of the batch in one persistent kernel (replaces gen_eye, the
+// extend / shade pairs and gen_light)
+hipError_t wf_paths(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t n_slots,
+                    uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
+hipError_t wf_paths_blocks_per_cu(bool lds_scene, size_t lds_bytes, int waves, int* out);
 hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                      uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
@@ -77,7 +87,8 @@ hipError_t wf_conn_accum(const SceneDev& sc, const GpuCamera& cam, const WfBuffe
 hipError_t wf_resolve(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, double* fb, const WfLaunchCfg& cfg,
                       hipStream_t st);
 
-hipError_t wf_persistent_blocks_per_cu(bool lds_scene, size_t lds_bytes, int* out);
+// sets the LDS limit of the traversal kernels for this launch shape and reports how many workgroups fit a CU
+hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu);
 
 }  // namespace bdpt
 #endif

@@ -19,23 +19,37 @@ BDPT_DEV uint32_t rank_in_mask(unsigned long long mask) {
     return __builtin_popcountll(mask & ((1ull << lane_id()) - 1ull));
 }
 
-// append with ONE atomic per workgroup: every wave contributes its count through LDS.  All threads of
-// the workgroup must call it together.  (A single queue counter saturates at under 100 atomics per
-// microsecond, so a queue fed by one atomic per wave costs ~0.7 ms per 4 M entries.)
-constexpr int kStageBlock = 1024;
-BDPT_DEV void block_append(bool flag, uint32_t value, uint32_t* queue, uint32_t* count, uint32_t* s_wave, uint32_t* s_base) {
-    const unsigned long long m = __ballot(flag);
+// Stage kernels work on tiles of kStageTile queue entries per 256-thread workgroup, four entries per
+// thread, and append to the output queue with ONE atomic per tile: every wave contributes its counts
+// through LDS.  (A single queue counter saturates at under 100 atomics per microsecond, so a queue fed
+// by one atomic per wave costs ~0.7 ms per 4 M entries.)  The workgroups stay small so that they fit
+// beside the resident waves of the persistent traversal kernels of the other batches in flight.
+// All threads of the workgroup must call tile_append together.
+constexpr int kStageBlock = 256;
+constexpr int kStagePerThread = 4;
+constexpr int kStageTile = kStageBlock * kStagePerThread;
+constexpr int kStageWaves = kStageBlock / 64;
+BDPT_DEV void tile_append(const bool (&flag)[kStagePerThread], const uint32_t (&value)[kStagePerThread], uint32_t* queue,
+                          uint32_t* count, uint32_t* s_wave, uint32_t* s_base) {
+    unsigned long long m[kStagePerThread];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < kStagePerThread; j++) { m[j] = __ballot(flag[j]); mine += (uint32_t)__builtin_popcountll(m[j]); }
     const uint32_t wave = threadIdx.x >> 6;
-    if (lane_id() == 0) s_wave[wave] = (uint32_t)__builtin_popcountll(m);
+    if (lane_id() == 0) s_wave[wave] = mine;        // `mine` is wave-uniform
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
-        const uint32_t n_waves = blockDim.x >> 6;
-        for (uint32_t w = 0; w < n_waves; w++) { const uint32_t t = s_wave[w]; s_wave[w] = run; run += t; }
+        for (uint32_t w = 0; w < (uint32_t)kStageWaves; w++) { const uint32_t t = s_wave[w]; s_wave[w] = run; run += t; }
         *s_base = run ? atomicAdd(count, run) : 0u;
     }
     __syncthreads();
-    if (flag) queue[*s_base + s_wave[wave] + rank_in_mask(m)] = value;
+    uint32_t at = *s_base + s_wave[wave];
+#pragma unroll
+    for (int j = 0; j < kStagePerThread; j++) {
+        if (flag[j]) queue[at + rank_in_mask(m[j])] = value[j];
+        at += (uint32_t)__builtin_popcountll(m[j]);
+    }
     __syncthreads();
 }
 
@@ -122,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb,
 //  * the root's own box (bvh.h:52 at the root) is not tested separately: it contains both child
 //    boxes, and the slab arithmetic is monotone, so a ray that passes a child box passes the root box.
 constexpr int kStackDepth = kWideStackDepth;
-constexpr size_t kTopLdsBytes = 32 * 1024;   // = kLdsTopSahNodes * 64 = kLdsTopWideNodes * 128
+constexpr size_t kTopLdsBytes = 32 * 1024;   // LDS copy of the top levels in the fused subpath kernel
 constexpr int32_t kPop = (int32_t)0x80000000;   // neither an interior index (>= 0) nor a leaf reference
 
 template <class NodeT>
@@ -331,10 +345,11 @@ BDPT_DEV void stage_tree(const NodeT* nodes, uint32_t n_nodes, const GpuTri* tri
 
 // SHADOW walks the reference's own tree (GpuWideNode): whether a visibility query is blocked depends on
 // that tree's boxes.  Closest-hit queries walk the surface-area-heuristic hierarchy (GpuSahNode).
-template <bool SHADOW, bool STATS, bool LDS_SCENE>
-__global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
-                                                     const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
-                                                     unsigned long long* stats, int refill_threshold, uint32_t chunk) {
+template <bool SHADOW, bool STATS, bool LDS_SCENE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
+                                                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
+                                                    unsigned long long* stats, int refill_threshold, uint32_t chunk,
+                                                    uint32_t top_nodes) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
     if (SHADOW) {
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
             traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, chunk);
         } else {
             GpuWideNode* l_nodes = reinterpret_cast<GpuWideNode*>(smem);
-            const uint32_t n_top = sc.n_wnodes < kLdsTopWideNodes ? sc.n_wnodes : kLdsTopWideNodes;
+            const uint32_t n_top = sc.n_wnodes < top_nodes / 2 ? sc.n_wnodes : top_nodes / 2;      // 128-byte records
             stage_tree(sc.wnodes, n_top, sc.stris, 0u, l_nodes, (GpuTri*)nullptr);
             TopLdsMem<GpuWideNode> mem{l_nodes, sc.wnodes, sc.stris, (int32_t)n_top};
             traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, chunk);
@@ -360,11 +375,240 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
             traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, chunk);
         } else {
             GpuSahNode* l_nodes = reinterpret_cast<GpuSahNode*>(smem);
-            const uint32_t n_top = sc.n_xnodes < kLdsTopSahNodes ? sc.n_xnodes : kLdsTopSahNodes;
+            const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
             stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
             TopLdsMem<GpuSahNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
             traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, chunk);
         }
+    }
+}
+
+// ------------------------------------------------------------------ both subpaths of a sample in one persistent kernel
+// A lane owns one sample from its camera ray to the end of its light subpath (camera.h:300-313): it
+// walks the closest-hit hierarchy for the current ray, waits until enough lanes of its wave have a
+// finished ray, shades together with them (vertex, emission, next ray; at the end of the eye subpath
+// the emitter sample and the first light ray), and takes the next sample from the batch cursor when
+// its own is complete.  No ray state goes through memory and no bounce waits for the slowest ray of
+// the batch.  The order of the operations of ONE sample - and so every random draw and every rounding -
+// is that of sample_radiance() up to the connection loop; what a sample leaves behind (stored
+// vertices, counts, the unconnected radiance) is what the connection kernels below read.
+constexpr int kLaneIdle = 0, kLaneWalk = 1, kLaneShade = 2;
+
+template <bool STATS, class Mem>
+BDPT_DEV void paths_loop(const Mem& mem, const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b,
+                         uint32_t n_slots, uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold,
+                         const uint32_t kChunk, const int kShadeThreshold) {
+    const int depth = cam.max_depth;
+    const uint64_t ns = wb.ns;
+    int state = kLaneIdle;
+    uint32_t slot = 0;
+    bool eye = true;
+    int remaining = 0;                 // bounces left in the current subpath
+    uint32_t cnt = 0;                  // stored-vertex counts and flags, layout of WfBuffers::counts
+    Rng rng;
+    rng.key = 0; rng.counter = 0;
+    V3 T = mk(0, 0, 0);
+    // traversal state
+    int32_t cur = kPop;
+    int sp = 0;
+    int32_t stk_node[kStackDepth];
+    double stk_lo[kStackDepth];
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
+    double ix = 0, iy = 0, iz = 0, closest = 0;
+    HitLite h;
+    h.t = 0; h.u = 0; h.v = 0; h.tri = -1;
+    int32_t best_pos = -1;
+    uint32_t pool_next = 0, pool_end = 0;     // wave-uniform
+    bool exhausted = (n_slots == 0);
+    uint32_t n_records = 0, n_box_hits = 0, n_tri = 0, n_tri_hits = 0, n_rays = 0, n_stored = 0;
+
+    auto start_ray = [&]() {
+        ix = 1.0 / d.x; iy = 1.0 / d.y; iz = 1.0 / d.z;       // aabb.h:48, once per ray
+        closest = kInf;
+        cur = 0; sp = 0;
+        h.tri = -1; best_pos = -1;
+        state = kLaneWalk;
+        if (STATS) n_rays++;
+    };
+
+    for (;;) {
+        // ---- new samples for idle lanes
+        const unsigned long long idle = __ballot(state == kLaneIdle);
+        const int n_idle = __builtin_popcountll(idle);
+        if (!exhausted && n_idle >= kRefillThreshold) {
+            if (pool_next == pool_end) {
+                uint32_t base = 0;
+                if (lane_id() == 0) base = atomicAdd(cursor, kChunk);
+                base = __shfl(base, 0, 64);
+                if (base >= n_slots) { exhausted = true; pool_next = pool_end = 0; }
+                else { pool_next = base; pool_end = (base + kChunk < n_slots) ? base + kChunk : n_slots; }
+            }
+            const uint32_t avail = pool_end - pool_next;
+            const uint32_t give = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
+            if (state == kLaneIdle) {
+                const uint32_t r = rank_in_mask(idle);
+                if (r < give) {
+                    slot = pool_next + r;
+                    int pi, pj, ps;
+                    if (slot_to_sample(cam, b, slot, pi, pj, ps)) {
+                        rng.key = stream_key(b.seed, (uint64_t)pj * (uint64_t)cam.width + (uint64_t)pi, (uint64_t)ps);
+                        rng.counter = 0;
+                        const int s_j = ps / cam.sqrt_spp, s_i = ps - s_j * cam.sqrt_spp;
+                        camera_ray(cam, pi, pj, s_i, s_j, rng, o, d);
+                        T = mk(1.0, 1.0, 1.0);
+                        eye = true;
+                        remaining = depth;
+                        cnt = 0;
+                        if (depth > 0) start_ray();
+                        else { h.tri = -1; state = kLaneShade; remaining = 0; }    // no bounce at all: straight to the subpath end
+                    } else {
+                        wb.counts[slot] = 0; wb.ctr[slot] = 0;
+                        wb.result[slot] = 0.0; wb.result[ns + slot] = 0.0; wb.result[2 * ns + slot] = 0.0;
+                    }
+                }
+            }
+            pool_next += give;
+        }
+        const unsigned long long walking = __ballot(state == kLaneWalk);
+        const unsigned long long pending = __ballot(state == kLaneShade);
+        if ((walking | pending) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- shading, once enough lanes wait for it (or nobody is walking)
+        if (pending && (__builtin_popcountll(pending) >= kShadeThreshold || walking == 0)) {
+            if (state == kLaneShade) {
+                bool subpath_ends = true;
+                V3 radiance = mk(0, 0, 0);          // eye subpath: background or emission term, written when it ends
+                if (remaining > 0) {
+                    if (h.tri < 0) {
+                        // camera.h:337-338: background_contrib (0) += throughput * background
+                        if (eye) radiance = add(mk(0, 0, 0), mulv(T, ld3(cam.background)));
+                    } else {
+                        HitLite hh = h;
+                        hh.tri = sc.stris[h.tri].pad;            // leaf position -> triangle id
+                        Bounce bo;
+                        shade_bounce<true>(sc, o, d, hh, T, rng, bo);
+                        cnt |= eye ? kCntEyeHit : kCntLightHit;
+                        if (bo.keep) {
+                            const uint32_t ne = cnt & 0xFFFu, nl = (cnt >> 12) & 0xFFFu;
+                            slot_store(wb, slot).put(eye ? (int)ne : depth + (int)nl, bo.vx);
+                            cnt += eye ? 1u : (1u << 12);
+                            if (STATS) n_stored++;
+                        }
+                        // result = background_contrib (0) + throughput * emission, camera.h:306-309
+                        if (eye && bo.emitted) radiance = add(mk(0, 0, 0), bo.emitted_term);
+                        remaining--;
+                        if (bo.cont && remaining > 0) {
+                            o = bo.o; d = bo.d; T = bo.T;
+                            start_ray();
+                            subpath_ends = false;
+                        }
+                    }
+                }
+                if (subpath_ends) {
+                    bool finished = true;
+                    if (eye) {
+                        wb.result[slot] = radiance.x; wb.result[ns + slot] = radiance.y; wb.result[2 * ns + slot] = radiance.z;
+                        // light subpath: camera.h:313 -> build_light_path -> trace_path(light_ray, depth - 1, ...)
+                        Emitter em;
+                        sample_emitter(sc, depth, rng, em);
+                        if (em.valid) {
+                            slot_store(wb, slot).put(depth, em.ev);
+                            if (STATS) n_stored++;
+                            cnt |= kCntLightValid | kCntLightHit | (1u << 12);
+                            if (em.has_ray && depth - 1 > 0) {
+                                o = em.o; d = em.d; T = em.T;
+                                eye = false;
+                                remaining = depth - 1;
+                                start_ray();
+                                finished = false;
+                            }
+                        }
+                    }
+                    if (finished) {
+                        wb.counts[slot] = cnt;
+                        wb.ctr[slot] = rng.counter;
+                        state = kLaneIdle;
+                    }
+                }
+            }
+            continue;      // refill / re-evaluate before the next walk step
+        }
+        // ---- one record (or leaf) of the ordered walk, see traverse_queue
+        if (state == kLaneWalk) {
+            if (cur >= 0) {
+                const auto nd = mem.wnode(cur);
+                if (STATS) n_records++;
+                double lo0, hi0, lo1, hi1;
+                slab(nd.lo0, nd.hi0, o, ix, iy, iz, closest, lo0, hi0);
+                slab(nd.lo1, nd.hi1, o, ix, iy, iz, closest, lo1, hi1);
+                const bool p0 = !(hi0 <= lo0), p1 = !(hi1 <= lo1);
+                if (STATS) n_box_hits += (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
+                if (p0 && p1) {
+                    const bool second_first = lo1 < lo0;
+                    stk_node[sp] = second_first ? nd.child0 : nd.child1;
+                    stk_lo[sp] = second_first ? lo0 : lo1;
+                    sp++;
+                    cur = second_first ? nd.child1 : nd.child0;
+                } else if (p0) cur = nd.child0;
+                else if (p1) cur = nd.child1;
+                else cur = kPop;
+            } else {
+                const uint32_t code = (uint32_t)~cur;
+                const uint32_t first = code >> 2;
+                const uint32_t n_here = 1u + (code & 3u);
+                for (uint32_t q = 0; q < n_here; q++) {
+                    const GpuTri tr = mem.stri(first + q);
+                    double t, u, v;
+                    const bool inside = tri_test(tr, o, d, 0.001, closest, t, u, v);
+                    if (STATS) { n_tri++; if (inside) n_tri_hits++; }
+                    if (inside && (t < closest || best_pos < 0 || tr.pad > best_pos)) {
+                        closest = t; h.t = t; h.u = u; h.v = v; best_pos = tr.pad; h.tri = tr.pad;
+                    }
+                }
+                cur = kPop;
+            }
+            if (cur == kPop) {
+                bool done = true;
+                while (sp > 0) {
+                    sp--;
+                    const double e_lo = stk_lo[sp];
+                    const int32_t e_node = stk_node[sp];
+                    if (!(closest <= e_lo)) { cur = e_node; done = false; break; }
+                }
+                if (done) state = kLaneShade;
+            }
+        }
+    }
+    if (STATS) {
+        flush_wave_counter(&stats[0], n_rays);
+        flush_wave_counter(&stats[1], 2ull * n_records);
+        flush_wave_counter(&stats[2], n_box_hits);
+        flush_wave_counter(&stats[3], n_records);            // in units of 64 bytes fetched
+        flush_wave_counter(&stats[4], n_tri);
+        flush_wave_counter(&stats[5], n_tri_hits);
+        flush_wave_counter(&stats[10], n_stored);
+    }
+}
+
+template <bool STATS, bool LDS_SCENE, int WAVES>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_paths(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, uint32_t n_slots,
+                                                  uint32_t* cursor, unsigned long long* stats, int refill_threshold,
+                                                  uint32_t chunk, int shade_threshold) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    GpuSahNode* l_nodes = reinterpret_cast<GpuSahNode*>(smem);
+    if (LDS_SCENE) {
+        GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
+        stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
+        TreeMem<GpuSahNode> mem{l_nodes, l_tris};
+        paths_loop<STATS>(mem, sc, cam, wb, b, n_slots, cursor, stats, refill_threshold, chunk, shade_threshold);
+    } else {
+        constexpr uint32_t kTop = (uint32_t)(kTopLdsBytes / sizeof(GpuSahNode));
+        const uint32_t n_top = sc.n_xnodes < kTop ? sc.n_xnodes : kTop;
+        stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
+        TopLdsMem<GpuSahNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
+        paths_loop<STATS>(mem, sc, cam, wb, b, n_slots, cursor, stats, refill_threshold, chunk, shade_threshold);
     }
 }
 
@@ -373,60 +617,63 @@ template <bool EYE, bool STATS>
 __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
                                                   const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
                                                   uint32_t* count_out, int last_bounce, unsigned long long* stats) {
-    __shared__ uint32_t s_wave[kStageBlock / 64];
+    __shared__ uint32_t s_wave[kStageWaves];
     __shared__ uint32_t s_base;
     const uint32_t count = count_in_ptr ? *count_in_ptr : count_in_imm;
     const uint64_t ns = wb.ns;
     const int depth = cam.max_depth;
     uint32_t n_stored = 0;
     // whole workgroups iterate together so that the append sees every thread
-    const uint32_t rounded = (count + (kStageBlock - 1)) & ~(uint32_t)(kStageBlock - 1);
-    for (uint32_t k = blockIdx.x * kStageBlock + threadIdx.x; k < rounded; k += gridDim.x * kStageBlock) {
-        bool cont = false;
-        uint32_t slot = 0;
-        if (k < count) {
-            slot = queue_in ? queue_in[k] : k;
+    for (uint32_t tile = blockIdx.x * kStageTile; tile < count; tile += gridDim.x * kStageTile) {
+        bool cont[kStagePerThread];
+        uint32_t slots[kStagePerThread];
+#pragma unroll 1
+        for (int j = 0; j < kStagePerThread; j++) {
+            const uint32_t k = tile + (uint32_t)j * kStageBlock + threadIdx.x;
+            cont[j] = false;
+            slots[j] = 0;
+            if (k >= count) continue;
+            const uint32_t slot = queue_in ? queue_in[k] : k;
+            slots[j] = slot;
             int pi, pj, ps;
-            const bool active = slot_to_sample(cam, b, slot, pi, pj, ps);
+            if (!slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
             const int32_t tri = wb.hit_tri[slot];
-            if (active) {
-                V3 T = mk(wb.thr[slot], wb.thr[ns + slot], wb.thr[2 * ns + slot]);
-                if (tri < 0) {
-                    if (EYE) {   // camera.h:337-338: background_contrib (0) += throughput * background
-                        V3 bg = add(mk(0, 0, 0), mulv(T, ld3(cam.background)));
-                        wb.result[slot] = bg.x; wb.result[ns + slot] = bg.y; wb.result[2 * ns + slot] = bg.z;
-                    }
-                } else {
-                    V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
-                    V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
-                    HitLite h;
-                    h.tri = tri; h.t = wb.hit[slot]; h.u = wb.hit[ns + slot]; h.v = wb.hit[2 * ns + slot];
-                    Rng rng = slot_rng(cam, b, slot, wb.ctr[slot]);
-                    Bounce bo;
-                    shade_bounce<EYE>(sc, o, d, h, T, rng, bo);
-                    uint32_t cnt = wb.counts[slot] | (EYE ? kCntEyeHit : kCntLightHit);
-                    if (bo.keep) {
-                        const uint32_t ne = cnt & 0xFFFu, nl = (cnt >> 12) & 0xFFFu;
-                        slot_store(wb, slot).put(EYE ? (int)ne : depth + (int)nl, bo.vx);
-                        cnt += EYE ? 1u : (1u << 12);
-                        if (STATS) n_stored++;
-                    }
-                    wb.counts[slot] = cnt;
-                    if (EYE && bo.emitted) {   // result = background_contrib (0) + throughput * emission
-                        V3 e = add(mk(0, 0, 0), bo.emitted_term);
-                        wb.result[slot] = e.x; wb.result[ns + slot] = e.y; wb.result[2 * ns + slot] = e.z;
-                    }
-                    wb.ctr[slot] = rng.counter;
-                    if (bo.cont && !last_bounce) {
-                        cont = true;
-                        wb.ray[slot] = bo.o.x; wb.ray[ns + slot] = bo.o.y; wb.ray[2 * ns + slot] = bo.o.z;
-                        wb.ray[3 * ns + slot] = bo.d.x; wb.ray[4 * ns + slot] = bo.d.y; wb.ray[5 * ns + slot] = bo.d.z;
-                        wb.thr[slot] = bo.T.x; wb.thr[ns + slot] = bo.T.y; wb.thr[2 * ns + slot] = bo.T.z;
-                    }
+            V3 T = mk(wb.thr[slot], wb.thr[ns + slot], wb.thr[2 * ns + slot]);
+            if (tri < 0) {
+                if (EYE) {   // camera.h:337-338: background_contrib (0) += throughput * background
+                    V3 bg = add(mk(0, 0, 0), mulv(T, ld3(cam.background)));
+                    wb.result[slot] = bg.x; wb.result[ns + slot] = bg.y; wb.result[2 * ns + slot] = bg.z;
                 }
+                continue;
+            }
+            V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
+            V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
+            HitLite h;
+            h.tri = tri; h.t = wb.hit[slot]; h.u = wb.hit[ns + slot]; h.v = wb.hit[2 * ns + slot];
+            Rng rng = slot_rng(cam, b, slot, wb.ctr[slot]);
+            Bounce bo;
+            shade_bounce<EYE>(sc, o, d, h, T, rng, bo);
+            uint32_t cnt = wb.counts[slot] | (EYE ? kCntEyeHit : kCntLightHit);
+            if (bo.keep) {
+                const uint32_t ne = cnt & 0xFFFu, nl = (cnt >> 12) & 0xFFFu;
+                slot_store(wb, slot).put(EYE ? (int)ne : depth + (int)nl, bo.vx);
+                cnt += EYE ? 1u : (1u << 12);
+                if (STATS) n_stored++;
+            }
+            wb.counts[slot] = cnt;
+            if (EYE && bo.emitted) {   // result = background_contrib (0) + throughput * emission
+                V3 e = add(mk(0, 0, 0), bo.emitted_term);
+                wb.result[slot] = e.x; wb.result[ns + slot] = e.y; wb.result[2 * ns + slot] = e.z;
+            }
+            wb.ctr[slot] = rng.counter;
+            if (bo.cont && !last_bounce) {
+                cont[j] = true;
+                wb.ray[slot] = bo.o.x; wb.ray[ns + slot] = bo.o.y; wb.ray[2 * ns + slot] = bo.o.z;
+                wb.ray[3 * ns + slot] = bo.d.x; wb.ray[4 * ns + slot] = bo.d.y; wb.ray[5 * ns + slot] = bo.d.z;
+                wb.thr[slot] = bo.T.x; wb.thr[ns + slot] = bo.T.y; wb.thr[2 * ns + slot] = bo.T.z;
             }
         }
-        block_append(cont, slot, queue_out, count_out, s_wave, &s_base);
+        tile_append(cont, slots, queue_out, count_out, s_wave, &s_base);
     }
     if (STATS) flush_wave_counter(&stats[10], n_stored);
 }
@@ -439,31 +686,35 @@ __global__ __launch_bounds__(kStageBlock) void k_gen_light(SceneDev sc, GpuCamer
     const uint32_t n = (uint32_t)b.pixels_stride * spp;
     const uint64_t ns = wb.ns;
     const int depth = cam.max_depth;
-    __shared__ uint32_t s_wave[kStageBlock / 64];
+    __shared__ uint32_t s_wave[kStageWaves];
     __shared__ uint32_t s_base;
-    const uint32_t rounded = (n + (kStageBlock - 1)) & ~(uint32_t)(kStageBlock - 1);
     uint32_t n_stored = 0;
-    for (uint32_t slot = blockIdx.x * kStageBlock + threadIdx.x; slot < rounded; slot += gridDim.x * kStageBlock) {
-        bool cont = false;
-        int pi, pj, ps;
-        if (slot < n && slot_to_sample(cam, b, slot, pi, pj, ps)) {
+    for (uint32_t tile = blockIdx.x * kStageTile; tile < n; tile += gridDim.x * kStageTile) {
+        bool cont[kStagePerThread];
+        uint32_t slots[kStagePerThread];
+#pragma unroll 1
+        for (int j = 0; j < kStagePerThread; j++) {
+            const uint32_t slot = tile + (uint32_t)j * kStageBlock + threadIdx.x;
+            cont[j] = false;
+            slots[j] = slot;
+            int pi, pj, ps;
+            if (slot >= n || !slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
             Rng rng = slot_rng(cam, b, slot, wb.ctr[slot]);
             Emitter em;
             sample_emitter(sc, depth, rng, em);
             wb.ctr[slot] = rng.counter;
-            if (em.valid) {
-                slot_store(wb, slot).put(depth, em.ev);
-                if (STATS) n_stored++;
-                wb.counts[slot] = wb.counts[slot] | kCntLightValid | kCntLightHit | (1u << 12);
-                if (em.has_ray && depth - 1 > 0) {
-                    cont = true;
-                    wb.ray[slot] = em.o.x; wb.ray[ns + slot] = em.o.y; wb.ray[2 * ns + slot] = em.o.z;
-                    wb.ray[3 * ns + slot] = em.d.x; wb.ray[4 * ns + slot] = em.d.y; wb.ray[5 * ns + slot] = em.d.z;
-                    wb.thr[slot] = em.T.x; wb.thr[ns + slot] = em.T.y; wb.thr[2 * ns + slot] = em.T.z;
-                }
+            if (!em.valid) continue;
+            slot_store(wb, slot).put(depth, em.ev);
+            if (STATS) n_stored++;
+            wb.counts[slot] = wb.counts[slot] | kCntLightValid | kCntLightHit | (1u << 12);
+            if (em.has_ray && depth - 1 > 0) {
+                cont[j] = true;
+                wb.ray[slot] = em.o.x; wb.ray[ns + slot] = em.o.y; wb.ray[2 * ns + slot] = em.o.z;
+                wb.ray[3 * ns + slot] = em.d.x; wb.ray[4 * ns + slot] = em.d.y; wb.ray[5 * ns + slot] = em.d.z;
+                wb.thr[slot] = em.T.x; wb.thr[ns + slot] = em.T.y; wb.thr[2 * ns + slot] = em.T.z;
             }
         }
-        block_append(cont, slot, queue_out, count_out, s_wave, &s_base);
+        tile_append(cont, slots, queue_out, count_out, s_wave, &s_base);
     }
     if (STATS) flush_wave_counter(&stats[10], n_stored);
 }
@@ -476,14 +727,19 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_prepare(GpuCamera cam, WfB
     const uint32_t spp = (uint32_t)(cam.sqrt_spp * cam.sqrt_spp);
     const uint32_t n = (uint32_t)b.pixels_stride * spp;
     const uint64_t ns = wb.ns;
-    __shared__ uint32_t s_wave[kStageBlock / 64];
+    __shared__ uint32_t s_wave[kStageWaves];
     __shared__ uint32_t s_base;
-    const uint32_t rounded = (n + (kStageBlock - 1)) & ~(uint32_t)(kStageBlock - 1);
     unsigned long long draws = 0, samples = 0;
-    for (uint32_t slot = blockIdx.x * kStageBlock + threadIdx.x; slot < rounded; slot += gridDim.x * kStageBlock) {
-        bool want = false;
-        int pi, pj, ps;
-        if (slot < n && slot_to_sample(cam, b, slot, pi, pj, ps)) {
+    for (uint32_t tile = blockIdx.x * kStageTile; tile < n; tile += gridDim.x * kStageTile) {
+        bool want[kStagePerThread];
+        uint32_t slots[kStagePerThread];
+#pragma unroll
+        for (int j = 0; j < kStagePerThread; j++) {
+            const uint32_t slot = tile + (uint32_t)j * kStageBlock + threadIdx.x;
+            want[j] = false;
+            slots[j] = slot;
+            int pi, pj, ps;
+            if (slot >= n || !slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
             const uint32_t cnt = wb.counts[slot];
             if (STATS) { draws += wb.ctr[slot]; samples++; }
             if (cnt & kCntLightValid) {
@@ -494,50 +750,55 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_prepare(GpuCamera cam, WfB
                     wb.result[ns + slot] = wb.result[ns + slot] + 0.0;
                     wb.result[2 * ns + slot] = wb.result[2 * ns + slot] + 0.0;
                 }
-                want = (cnt & 0xFFFu) > 0 && ((cnt >> 12) & 0xFFFu) > 0;
+                want[j] = (cnt & 0xFFFu) > 0 && ((cnt >> 12) & 0xFFFu) > 0;
             }
         }
-        block_append(want, slot, wb.conn_queue, conn_count, s_wave, &s_base);
+        tile_append(want, slots, wb.conn_queue, conn_count, s_wave, &s_base);
     }
     if (STATS) { flush_wave_counter(&stats[8], draws); flush_wave_counter(&stats[9], samples); }
 }
 
 // shadow rays of eye vertex `a` against every light vertex of the sample.  Queue space is reserved
-// once per 1024-thread workgroup (one atomic) for every candidate pair; pairs that turn out to
-// contribute nothing without a ray leave an entry with a negative max_t, which the traversal skips.
-constexpr int kConnBlock = 1024;
+// once per tile (one atomic) for every candidate pair; pairs that turn out to contribute nothing
+// without a ray leave an entry with a negative max_t, which the traversal skips.
 template <bool STATS>
-__global__ __launch_bounds__(kConnBlock) void k_conn_gen(SceneDev sc, GpuCamera cam, WfBuffers wb, int a,
-                                                         const uint32_t* conn_count, uint32_t* shadow_count,
-                                                         unsigned long long* stats) {
-    __shared__ uint32_t s_wave_off[kConnBlock / 64];
+__global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera cam, WfBuffers wb, int a,
+                                                          const uint32_t* conn_count, uint32_t* shadow_count,
+                                                          unsigned long long* stats) {
+    __shared__ uint32_t s_wave_off[kStageWaves];
     __shared__ uint32_t s_base;
     const uint32_t count = *conn_count;
     const int depth = cam.max_depth;
-    const uint32_t rounded = (count + (kConnBlock - 1)) & ~(uint32_t)(kConnBlock - 1);
     const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t cap = wb.shadow_cap;
     uint32_t n_pairs = 0;
-    for (uint32_t k = blockIdx.x * kConnBlock + threadIdx.x; k < rounded; k += gridDim.x * kConnBlock) {
-        uint32_t slot = 0;
-        int n_light = 0;
-        Vertex cv;
-        bool cam_ok = false;
-        if (k < count) {
-            slot = wb.conn_queue[k];
-            const uint32_t cnt = wb.counts[slot];
-            if ((uint32_t)a < (cnt & 0xFFFu)) {
-                n_light = (int)((cnt >> 12) & 0xFFFu);
-                for (uint32_t w = 0; w < wb.vis_words; w++) wb.vis[(uint64_t)w * wb.ns + slot] = 0ull;
-                cv = slot_store(wb, slot).get(a);
-                if (STATS) n_pairs += (uint32_t)n_light;
-                // an eye vertex on an emitter has a zero BSDF (material.h:35-37): every pair it forms
-                // contributes zero whatever the visibility, so no ray is spent on it
-                cam_ok = !(cv.info & kVtxIsLight);
+    for (uint32_t tile = blockIdx.x * kStageTile; tile < count; tile += gridDim.x * kStageTile) {
+        // pass 1: how many candidate pairs each of this thread's entries has
+        uint32_t slots[kStagePerThread], mine[kStagePerThread];
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < kStagePerThread; j++) {
+            const uint32_t k = tile + (uint32_t)j * kStageBlock + threadIdx.x;
+            slots[j] = 0;
+            mine[j] = 0;
+            if (k < count) {
+                const uint32_t slot = wb.conn_queue[k];
+                slots[j] = slot;
+                const uint32_t cnt = wb.counts[slot];
+                if ((uint32_t)a < (cnt & 0xFFFu)) {
+                    const uint32_t n_light = (cnt >> 12) & 0xFFFu;
+                    for (uint32_t w = 0; w < wb.vis_words; w++) wb.vis[(uint64_t)w * wb.ns + slot] = 0ull;
+                    if (STATS) n_pairs += n_light;
+                    // an eye vertex on an emitter has a zero BSDF (material.h:35-37): every pair it forms
+                    // contributes zero whatever the visibility, so no ray is spent on it
+                    const uint32_t info = (uint32_t)__double_as_longlong(wb.vtx[((uint64_t)a * kVtxDoubles + 9) * wb.ns + slot]);
+                    if (!(info & kVtxIsLight)) mine[j] = n_light;
+                }
             }
+            total += mine[j];
         }
-        const uint32_t mine = cam_ok ? (uint32_t)n_light : 0u;
-        // workgroup-wide exclusive scan of `mine`
-        uint32_t incl = mine;
+        // workgroup-wide exclusive scan of `total`
+        uint32_t incl = total;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t v = __shfl_up(incl, off, 64);
@@ -547,24 +808,30 @@ __global__ __launch_bounds__(kConnBlock) void k_conn_gen(SceneDev sc, GpuCamera 
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t run = 0;
-            for (int w = 0; w < kConnBlock / 64; w++) { const uint32_t t = s_wave_off[w]; s_wave_off[w] = run; run += t; }
+            for (int w = 0; w < kStageWaves; w++) { const uint32_t t = s_wave_off[w]; s_wave_off[w] = run; run += t; }
             s_base = run ? atomicAdd(shadow_count, run) : 0u;
         }
         __syncthreads();
-        uint64_t e = (uint64_t)s_base + s_wave_off[wave] + incl - mine;
-        const uint64_t cap = wb.shadow_cap;
-        for (uint32_t bi = 0; bi < mine; bi++, e++) {
-            const Vertex lv = slot_store(wb, slot).get(depth + (int)bi);
-            PairGeom g;
-            V3 f_cam, f_light;
-            const bool emit = pair_geometry(cv, lv, g) && pair_factors(sc, cv, lv, f_cam, f_light);
-            if (emit) {
-                wb.shadow[e] = g.origin.x; wb.shadow[cap + e] = g.origin.y; wb.shadow[2 * cap + e] = g.origin.z;
-                wb.shadow[3 * cap + e] = g.dir_unit.x; wb.shadow[4 * cap + e] = g.dir_unit.y; wb.shadow[5 * cap + e] = g.dir_unit.z;
-                wb.shadow[6 * cap + e] = g.max_t;
-                wb.shadow[7 * cap + e] = __longlong_as_double((long long)(((unsigned long long)slot << 16) | bi));
-            } else {
-                wb.shadow[6 * cap + e] = -1.0;
+        uint64_t e = (uint64_t)s_base + s_wave_off[wave] + incl - total;
+        // pass 2: the rays
+#pragma unroll 1
+        for (int j = 0; j < kStagePerThread; j++) {
+            if (mine[j] == 0) continue;
+            const uint32_t slot = slots[j];
+            const Vertex cv = slot_store(wb, slot).get(a);
+            for (uint32_t bi = 0; bi < mine[j]; bi++, e++) {
+                const Vertex lv = slot_store(wb, slot).get(depth + (int)bi);
+                PairGeom g;
+                V3 f_cam, f_light;
+                const bool emit = pair_geometry(cv, lv, g) && pair_factors(sc, cv, lv, f_cam, f_light);
+                if (emit) {
+                    wb.shadow[e] = g.origin.x; wb.shadow[cap + e] = g.origin.y; wb.shadow[2 * cap + e] = g.origin.z;
+                    wb.shadow[3 * cap + e] = g.dir_unit.x; wb.shadow[4 * cap + e] = g.dir_unit.y; wb.shadow[5 * cap + e] = g.dir_unit.z;
+                    wb.shadow[6 * cap + e] = g.max_t;
+                    wb.shadow[7 * cap + e] = __longlong_as_double((long long)(((unsigned long long)slot << 16) | bi));
+                } else {
+                    wb.shadow[6 * cap + e] = -1.0;
+                }
             }
         }
         __syncthreads();
@@ -621,12 +888,45 @@ __global__ __launch_bounds__(kBlock) void k_resolve(GpuCamera cam, WfBuffers wb,
 }  // namespace
 
 // ------------------------------------------------------------------------------ launchers
-hipError_t wf_persistent_blocks_per_cu(bool lds_scene, size_t lds_bytes, int* out) {
-    int n = 0;
-    hipError_t e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<false, false, true>, kBlock, lds_bytes)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<false, false, false>, kBlock, kTopLdsBytes);
-    *out = n < 1 ? 1 : n;
+// Traversal launch shape: scenes that fit LDS whole run 256-thread workgroups; larger scenes run
+// `trav_block`-thread workgroups that share an LDS copy of the first `top_nodes` 64-byte records.
+template <bool SHADOW, bool STATS, bool LDS_SCENE, int BLOCK>
+static hipError_t prepare_traverse(size_t shm, int* blocks_per_cu) {
+    auto fn = k_traverse<SHADOW, STATS, LDS_SCENE, BLOCK>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    if (blocks_per_cu) {
+        int n = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, BLOCK, shm);
+        *blocks_per_cu = n < 1 ? 1 : n;
+    }
     return e;
+}
+
+template <int BLOCK>
+static hipError_t prepare_traverse_block(size_t shm, int* blocks_per_cu) {
+    hipError_t e = prepare_traverse<false, false, false, BLOCK>(shm, blocks_per_cu);
+    if (e == hipSuccess) e = prepare_traverse<false, true, false, BLOCK>(shm, nullptr);
+    if (e == hipSuccess) e = prepare_traverse<true, false, false, BLOCK>(shm, nullptr);
+    if (e == hipSuccess) e = prepare_traverse<true, true, false, BLOCK>(shm, nullptr);
+    return e;
+}
+
+hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu) {
+    if (cfg.lds_scene) {
+        hipError_t e = prepare_traverse<false, false, true, 256>(cfg.lds_bytes, blocks_per_cu);
+        if (e == hipSuccess) e = prepare_traverse<false, true, true, 256>(cfg.lds_bytes, nullptr);
+        if (e == hipSuccess) e = prepare_traverse<true, false, true, 256>(cfg.lds_bytes, nullptr);
+        if (e == hipSuccess) e = prepare_traverse<true, true, true, 256>(cfg.lds_bytes, nullptr);
+        return e;
+    }
+    const size_t shm = (size_t)cfg.top_nodes * sizeof(GpuSahNode);
+    switch (cfg.trav_block) {
+        case 256: return prepare_traverse_block<256>(shm, blocks_per_cu);
+        case 512: return prepare_traverse_block<512>(shm, blocks_per_cu);
+        case 1024: return prepare_traverse_block<1024>(shm, blocks_per_cu);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const WfLaunchCfg& cfg,
@@ -635,20 +935,32 @@ hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers&
     return hipGetLastError();
 }
 
+template <bool SHADOW, bool STATS, bool LDS_SCENE, int BLOCK>
+static void launch_traverse_as(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
+                               uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
+                               hipStream_t st) {
+    const size_t shm = LDS_SCENE ? cfg.lds_bytes : (size_t)cfg.top_nodes * sizeof(GpuSahNode);
+    hipLaunchKernelGGL((k_traverse<SHADOW, STATS, LDS_SCENE, BLOCK>), dim3(cfg.persistent_blocks), dim3(BLOCK), shm, st, sc, wb,
+                       queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.top_nodes);
+}
+
+template <bool SHADOW, bool STATS>
+static hipError_t launch_traverse_stats(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
+                                        uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
+                                        hipStream_t st) {
+    if (cfg.lds_scene) launch_traverse_as<SHADOW, STATS, true, 256>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+    else if (cfg.trav_block == 256) launch_traverse_as<SHADOW, STATS, false, 256>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+    else if (cfg.trav_block == 512) launch_traverse_as<SHADOW, STATS, false, 512>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+    else launch_traverse_as<SHADOW, STATS, false, 1024>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+    return hipGetLastError();
+}
+
 template <bool SHADOW>
 static hipError_t launch_traverse(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                                   uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
                                   hipStream_t st) {
-    dim3 grid(cfg.persistent_blocks), block(kBlock);
-    const size_t shm = cfg.lds_scene ? cfg.lds_bytes : kTopLdsBytes;
-    if (stats) {
-        if (cfg.lds_scene) hipLaunchKernelGGL((k_traverse<SHADOW, true, true>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk);
-        else hipLaunchKernelGGL((k_traverse<SHADOW, true, false>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk);
-    } else {
-        if (cfg.lds_scene) hipLaunchKernelGGL((k_traverse<SHADOW, false, true>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk);
-        else hipLaunchKernelGGL((k_traverse<SHADOW, false, false>), grid, block, shm, st, sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk);
-    }
-    return hipGetLastError();
+    return stats ? launch_traverse_stats<SHADOW, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st)
+                 : launch_traverse_stats<SHADOW, false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
 }
 
 hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
@@ -661,10 +973,45 @@ hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* s
     return launch_traverse<true>(sc, wb, nullptr, shadow_count, 0, cursor, cfg, stats, st);
 }
 
+template <int WAVES>
+static hipError_t launch_paths(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t n_slots,
+                               uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
+    dim3 grid(cfg.paths_blocks), block(kBlock);
+    const size_t shm = cfg.lds_scene ? cfg.lds_bytes : kTopLdsBytes;
+    if (stats) {
+        if (cfg.lds_scene) hipLaunchKernelGGL((k_paths<true, true, WAVES>), grid, block, shm, st, sc, cam, wb, b, n_slots, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.shade_threshold);
+        else hipLaunchKernelGGL((k_paths<true, false, WAVES>), grid, block, shm, st, sc, cam, wb, b, n_slots, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.shade_threshold);
+    } else {
+        if (cfg.lds_scene) hipLaunchKernelGGL((k_paths<false, true, WAVES>), grid, block, shm, st, sc, cam, wb, b, n_slots, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.shade_threshold);
+        else hipLaunchKernelGGL((k_paths<false, false, WAVES>), grid, block, shm, st, sc, cam, wb, b, n_slots, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.shade_threshold);
+    }
+    return hipGetLastError();
+}
+
+hipError_t wf_paths(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t n_slots,
+                    uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
+    switch (cfg.paths_waves) {
+        case 2: return launch_paths<2>(sc, cam, wb, b, n_slots, cursor, cfg, stats, st);
+        case 3: return launch_paths<3>(sc, cam, wb, b, n_slots, cursor, cfg, stats, st);
+        default: return launch_paths<4>(sc, cam, wb, b, n_slots, cursor, cfg, stats, st);
+    }
+}
+
+hipError_t wf_paths_blocks_per_cu(bool lds_scene, size_t lds_bytes, int waves, int* out) {
+    int n = 0;
+    hipError_t e;
+    const size_t shm = lds_scene ? lds_bytes : kTopLdsBytes;
+    if (waves == 2) e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<false, true, 2>, kBlock, shm) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<false, false, 2>, kBlock, shm);
+    else if (waves == 3) e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<false, true, 3>, kBlock, shm) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<false, false, 3>, kBlock, shm);
+    else e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<false, true, 4>, kBlock, shm) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<false, false, 4>, kBlock, shm);
+    *out = n < 1 ? 1 : n;
+    return e;
+}
+
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
                     const uint32_t* queue_in, const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
                     uint32_t* count_out, bool last_bounce, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    dim3 grid(cfg.stream_blocks / 4), block(kStageBlock);
+    dim3 grid(cfg.stream_blocks), block(kStageBlock);
     const int last = last_bounce ? 1 : 0;
     if (eye) {
         if (stats) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, stats);
@@ -678,7 +1025,7 @@ hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& w
 
 hipError_t wf_gen_light(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* queue_out,
                         uint32_t* count_out, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    dim3 grid(cfg.stream_blocks / 4), block(kStageBlock);
+    dim3 grid(cfg.stream_blocks), block(kStageBlock);
     if (stats) hipLaunchKernelGGL((k_gen_light<true>), grid, block, 0, st, sc, cam, wb, b, queue_out, count_out, stats);
     else hipLaunchKernelGGL((k_gen_light<false>), grid, block, 0, st, sc, cam, wb, b, queue_out, count_out, stats);
     return hipGetLastError();
@@ -686,7 +1033,7 @@ hipError_t wf_gen_light(const SceneDev& sc, const GpuCamera& cam, const WfBuffer
 
 hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* conn_count,
                            const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    dim3 grid(cfg.stream_blocks / 4), block(kStageBlock);
+    dim3 grid(cfg.stream_blocks), block(kStageBlock);
     if (stats) hipLaunchKernelGGL((k_conn_prepare<true>), grid, block, 0, st, cam, wb, b, conn_count, stats);
     else hipLaunchKernelGGL((k_conn_prepare<false>), grid, block, 0, st, cam, wb, b, conn_count, stats);
     return hipGetLastError();
@@ -694,7 +1041,7 @@ hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBa
 
 hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
                        uint32_t* shadow_count, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    dim3 grid(cfg.stream_blocks / 2), block(kConnBlock);
+    dim3 grid(cfg.stream_blocks), block(kStageBlock);
     if (stats) hipLaunchKernelGGL((k_conn_gen<true>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
     else hipLaunchKernelGGL((k_conn_gen<false>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
     return hipGetLastError();
