@@ -259,6 +259,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     per_cu = env_int("BDPT_WF_BLOCKS_PER_CU", per_cu);
     cfg.persistent_blocks = ctx->cu_count * per_cu;
     cfg.refill_threshold = env_int("BDPT_WF_REFILL", 16);
+    cfg.leaf_threshold = env_int("BDPT_WF_LEAF", 24);
     cfg.chunk = (uint32_t)env_int("BDPT_WF_CHUNK", 128);
     cfg.stream_blocks = ctx->cu_count * 8;
     const bool staged = env_int("BDPT_WF_STAGED", 1) != 0;      // one kernel per bounce and stage instead of the fused subpath kernel

@@ -182,15 +182,20 @@ BDPT_DEV void slab(const T* blo, const T* bhi, V3 o, double ix, double iy, doubl
     }
 }
 
-// One loop iteration = one record (or leaf) visit of every lane that holds a ray.  SHADOW: rays come
-// from the shadow queue, the walk stops at the first accepted triangle and a clear ray sets its
-// pair's visibility bit.
+// One loop iteration is EITHER one interior record for every lane that stands at one, OR one triangle
+// for every lane that stands at a leaf: a wave executes both sides of a divergent branch one after the
+// other, so mixing the two in one iteration would run the (long) triangle test for a handful of lanes
+// every time.  Lanes that reach a leaf wait until `leaf_threshold` lanes of the wave have one (or no lane
+// has an interior record left).  SHADOW: rays come from the shadow queue, the walk stops at the first
+// accepted triangle and a clear ray sets its pair's visibility bit.
 template <bool SHADOW, bool STATS, class Mem>
 BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffers& wb, const uint32_t* queue, uint32_t count,
-                             uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk) {
+                             uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk,
+                             const int kLeafThreshold) {
     bool has = false;
     uint32_t slot = 0;
-    int32_t cur = kPop;
+    int32_t cur = kPop;                 // interior record to visit next (when leaf_left == 0)
+    uint32_t leaf_next = 0, leaf_left = 0;   // triangles of the current leaf still to test
     int sp = 0;
     int32_t stk_node[kStackDepth];
     double stk_lo[kStackDepth];
@@ -239,6 +244,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
                         ix = 1.0 / d.x; iy = 1.0 / d.y; iz = 1.0 / d.z;       // aabb.h:48, once per ray
                         closest = tmax0;
                         cur = 0;
+                        leaf_left = 0;
                         sp = 0;
                         h.tri = -1;
                         best_pos = -1;
@@ -249,13 +255,16 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
             }
             pool_next += give;
         }
-        if (__ballot(has) == 0) {
+        const unsigned long long active = __ballot(has);
+        if (active == 0) {
             if (exhausted) break;
             continue;
         }
-        if (has) {
-            bool done = false;
-            if (cur >= 0) {
+        const unsigned long long at_leaf = __ballot(has && leaf_left > 0);
+        const bool leaf_phase = (at_leaf == active) || (__builtin_popcountll(at_leaf) >= kLeafThreshold);
+        bool pop = false, done = false;
+        if (!leaf_phase) {
+            if (has && leaf_left == 0) {
                 const auto nd = mem.wnode(cur);
                 if (STATS) n_records++;
                 double lo0, hi0, lo1, hi1;
@@ -265,59 +274,61 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
                 if (STATS) n_box_hits += (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
                 if (p0 && p1) {
                     const bool second_first = lo1 < lo0;
-                    const int32_t near_c = second_first ? nd.child1 : nd.child0;
-                    const int32_t far_c = second_first ? nd.child0 : nd.child1;
-                    const double far_lo = second_first ? lo0 : lo1;
-                    stk_node[sp] = far_c; stk_lo[sp] = far_lo;      // sp < tree depth <= kStackDepth (checked by the host)
+                    stk_node[sp] = second_first ? nd.child0 : nd.child1;    // sp < tree depth <= kStackDepth (checked by the host)
+                    stk_lo[sp] = second_first ? lo0 : lo1;
                     sp++;
-                    cur = near_c;
+                    cur = second_first ? nd.child1 : nd.child0;
                 } else if (p0) cur = nd.child0;
                 else if (p1) cur = nd.child1;
-                else cur = kPop;
+                else pop = true;
+            }
+        } else {
+            if (has && leaf_left > 0) {
+                const GpuTri tr = mem.stri(leaf_next);
+                leaf_next++;
+                leaf_left--;
+                double t, u, v;
+                // triangle.h:63: accepted when tmin <= t <= closest (inclusive)
+                const bool inside = tri_test(tr, o, d, 0.001, closest, t, u, v);
+                if (STATS) { n_tri++; if (inside) n_tri_hits++; }
+                if (inside) {
+                    if (SHADOW) { h.tri = tr.pad; done = true; leaf_left = 0; }
+                    // equal t: the reference keeps the triangle it visits later = larger position in
+                    // its leaf order (tr.pad)
+                    else if (t < closest || best_pos < 0 || tr.pad > best_pos) {
+                        closest = t; h.t = t; h.u = u; h.v = v; best_pos = tr.pad; h.tri = tr.pad;
+                    }
+                }
+                if (leaf_left == 0 && !done) pop = true;
+            }
+        }
+        if (pop) {
+            done = true;
+            while (sp > 0) {
+                sp--;
+                const double e_lo = stk_lo[sp];
+                const int32_t e_node = stk_node[sp];
+                if (!(closest <= e_lo)) { cur = e_node; done = false; break; }    // aabb.h:61 with the current bound
+            }
+        }
+        if (has && !done && leaf_left == 0 && cur < 0) {      // arrived at a leaf: ~cur = (first << 2) | (count - 1)
+            const uint32_t code = (uint32_t)~cur;
+            leaf_next = code >> 2;
+            leaf_left = 1u + (code & 3u);
+        }
+        if (done) {
+            if (SHADOW) {
+                if (h.tri < 0) {       // nothing in the way: the pair is visible
+                    const uint32_t s = (uint32_t)(tag >> 16);
+                    const uint32_t bidx = (uint32_t)(tag & 0xFFFFu);
+                    atomicOr(&wb.vis[(uint64_t)(bidx >> 6) * wb.ns + s], 1ull << (bidx & 63u));
+                }
             } else {
-                const uint32_t code = (uint32_t)~cur;
-                const uint32_t first = code >> 2;
-                const uint32_t n_here = 1u + (code & 3u);
-                for (uint32_t q = 0; q < n_here; q++) {
-                    const GpuTri tr = mem.stri(first + q);
-                    double t, u, v;
-                    // triangle.h:63: accepted when tmin <= t <= closest (inclusive)
-                    const bool inside = tri_test(tr, o, d, 0.001, closest, t, u, v);
-                    if (STATS) { n_tri++; if (inside) n_tri_hits++; }
-                    if (inside) {
-                        if (SHADOW) { h.tri = tr.pad; done = true; break; }
-                        // equal t: the reference keeps the triangle it visits later = larger position in
-                        // its leaf order (tr.pad)
-                        if (t < closest || best_pos < 0 || tr.pad > best_pos) {
-                            closest = t; h.t = t; h.u = u; h.v = v; best_pos = tr.pad; h.tri = tr.pad;
-                        }
-                    }
-                }
-                cur = kPop;
+                const uint64_t ns = wb.ns;
+                wb.hit_tri[slot] = (h.tri >= 0) ? stris[h.tri].pad : -1;      // leaf position -> triangle id
+                if (h.tri >= 0) { wb.hit[slot] = h.t; wb.hit[ns + slot] = h.u; wb.hit[2 * ns + slot] = h.v; }
             }
-            if (!done && cur == kPop) {
-                done = true;
-                while (sp > 0) {
-                    sp--;
-                    const double e_lo = stk_lo[sp];
-                    const int32_t e_node = stk_node[sp];
-                    if (!(closest <= e_lo)) { cur = e_node; done = false; break; }    // aabb.h:61 with the current bound
-                }
-            }
-            if (done) {
-                if (SHADOW) {
-                    if (h.tri < 0) {       // nothing in the way: the pair is visible
-                        const uint32_t s = (uint32_t)(tag >> 16);
-                        const uint32_t bidx = (uint32_t)(tag & 0xFFFFu);
-                        atomicOr(&wb.vis[(uint64_t)(bidx >> 6) * wb.ns + s], 1ull << (bidx & 63u));
-                    }
-                } else {
-                    const uint64_t ns = wb.ns;
-                    wb.hit_tri[slot] = (h.tri >= 0) ? stris[h.tri].pad : -1;      // leaf position -> triangle id
-                    if (h.tri >= 0) { wb.hit[slot] = h.t; wb.hit[ns + slot] = h.u; wb.hit[2 * ns + slot] = h.v; }
-                }
-                has = false;
-            }
+            has = false;
         }
     }
     if (STATS) {
@@ -328,6 +339,16 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
         flush_wave_counter(&stats[4], n_tri);
         flush_wave_counter(&stats[5], n_tri_hits);
     }
+}
+
+// Rays a wave takes from the cursor at a time: the configured chunk while the queue is long, an even
+// share (at least 16) when it is short, so that the last rays of a short queue are spread over all
+// waves instead of waiting their turn inside a few.
+BDPT_DEV uint32_t fair_chunk(uint32_t count, uint32_t chunk) {
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    uint32_t share = (count / n_waves + 15u) & ~15u;
+    if (share < 16u) share = 16u;
+    return share < chunk ? share : chunk;
 }
 
 template <class NodeT>
@@ -349,7 +370,7 @@ template <bool SHADOW, bool STATS, bool LDS_SCENE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
                                                     const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                     unsigned long long* stats, int refill_threshold, uint32_t chunk,
-                                                    uint32_t top_nodes) {
+                                                    uint32_t top_nodes, int leaf_threshold) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
     if (SHADOW) {
@@ -358,13 +379,13 @@ __global__ __launch_bounds__(BLOCK) void k_traverse(SceneDev sc, WfBuffers wb, c
             GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_wnodes);
             stage_tree(sc.wnodes, sc.n_wnodes, sc.stris, sc.n_tris, l_nodes, l_tris);
             TreeMem<GpuWideNode> mem{l_nodes, l_tris};
-            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, chunk);
+            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold);
         } else {
             GpuWideNode* l_nodes = reinterpret_cast<GpuWideNode*>(smem);
             const uint32_t n_top = sc.n_wnodes < top_nodes / 2 ? sc.n_wnodes : top_nodes / 2;      // 128-byte records
             stage_tree(sc.wnodes, n_top, sc.stris, 0u, l_nodes, (GpuTri*)nullptr);
             TopLdsMem<GpuWideNode> mem{l_nodes, sc.wnodes, sc.stris, (int32_t)n_top};
-            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, chunk);
+            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold);
         }
     } else {
         if (LDS_SCENE) {
@@ -372,13 +393,13 @@ __global__ __launch_bounds__(BLOCK) void k_traverse(SceneDev sc, WfBuffers wb, c
             GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
             stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
             TreeMem<GpuSahNode> mem{l_nodes, l_tris};
-            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, chunk);
+            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold);
         } else {
             GpuSahNode* l_nodes = reinterpret_cast<GpuSahNode*>(smem);
             const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
             stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
             TopLdsMem<GpuSahNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
-            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, chunk);
+            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold);
         }
     }
 }
@@ -941,7 +962,7 @@ static void launch_traverse_as(const SceneDev& sc, const WfBuffers& wb, const ui
                                hipStream_t st) {
     const size_t shm = LDS_SCENE ? cfg.lds_bytes : (size_t)cfg.top_nodes * sizeof(GpuSahNode);
     hipLaunchKernelGGL((k_traverse<SHADOW, STATS, LDS_SCENE, BLOCK>), dim3(cfg.persistent_blocks), dim3(BLOCK), shm, st, sc, wb,
-                       queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.top_nodes);
+                       queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.top_nodes, cfg.leaf_threshold);
 }
 
 template <bool SHADOW, bool STATS>
