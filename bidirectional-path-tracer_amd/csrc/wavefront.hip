@@ -161,6 +161,17 @@ struct TopLdsMem {
     BDPT_DEV GpuTri stri(uint32_t i) const { return st[i]; }
 };
 
+// FP32 boxes (closest-hit hierarchy) only have to be conservative, not the reference's own tests: the
+// same intervals with min/max instructions instead of compare + select pairs.
+BDPT_DEV void slab(const float* blo, const float* bhi, V3 o, double ix, double iy, double iz, double closest, double& lo,
+                   double& hi) {
+    const double x0 = ((double)blo[0] - o.x) * ix, x1 = ((double)bhi[0] - o.x) * ix;
+    const double y0 = ((double)blo[1] - o.y) * iy, y1 = ((double)bhi[1] - o.y) * iy;
+    const double z0 = ((double)blo[2] - o.z) * iz, z1 = ((double)bhi[2] - o.z) * iz;
+    lo = __builtin_fmax(__builtin_fmax(__builtin_fmin(x0, x1), __builtin_fmin(y0, y1)), __builtin_fmax(__builtin_fmin(z0, z1), 0.001));
+    hi = __builtin_fmin(__builtin_fmin(__builtin_fmax(x0, x1), __builtin_fmax(y0, y1)), __builtin_fmin(__builtin_fmax(z0, z1), closest));
+}
+
 template <class T>
 BDPT_DEV void slab(const T* blo, const T* bhi, V3 o, double ix, double iy, double iz, double closest, double& lo,
                    double& hi) {
