@@ -51,22 +51,24 @@ struct GpuWideNode {
 static_assert(sizeof(GpuWideNode) == 128, "GpuWideNode must stay 128 bytes");
 
 // Closest-hit queries do not depend on the shape of the tree (the answer is the nearest accepted
-// triangle, ties resolved by the reference's leaf order), so they use a separate hierarchy built
-// with a binned surface-area heuristic: 64-byte records, both child boxes in FP32 rounded OUTWARD
-// (a box here always contains the padded FP64 box of everything below it, so culling is
-// conservative), leaves of up to four triangles, same child reference encoding as GpuWideNode.
+// triangle, ties resolved by the reference's leaf order), so they use a separate hierarchy: a binned
+// surface-area-heuristic tree collapsed to four children per record.  128-byte records, child boxes in
+// FP32 rounded OUTWARD (a box here always contains the padded FP64 box of everything below it, so
+// culling is conservative), leaves of up to four triangles.  Child reference: >= 0 index of an interior
+// record; kQuadEmpty for an unused slot; otherwise a leaf, ~ref = (first << 2) | (count - 1).
 // The triangle tests stay the reference's FP64 arithmetic.
-struct GpuSahNode {
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
-    int32_t child0, child1;
-    int32_t pad[2];
+struct GpuQuadNode {
+    float lo[4][3];
+    float hi[4][3];
+    int32_t child[4];
+    int32_t pad[4];
 };
-static_assert(sizeof(GpuSahNode) == 64, "GpuSahNode must stay 64 bytes");
+static_assert(sizeof(GpuQuadNode) == 128, "GpuQuadNode must stay 128 bytes");
+constexpr int32_t kQuadEmpty = (int32_t)0x80000000;
 
 // Records [0, kLdsTop*) of the two hierarchies are the levels nearest the root in breadth-first order; the
-// traversal kernels copy a prefix of them (up to 128 KiB) into LDS, so only the deeper visits go to L1/L2.
-constexpr uint32_t kLdsTopSahNodes = 2048;
+// traversal kernels copy a prefix of them into LDS, so only the deeper visits go to L1/L2.
+constexpr uint32_t kLdsTopQuadNodes = 1024;
 constexpr uint32_t kLdsTopWideNodes = 1024;
 
 // Read once per accepted hit / light sample: unit normal and area (triangle.h:26-29).
@@ -99,7 +101,7 @@ struct SceneDev {
     const GpuWideNode* wnodes;      // ordered-traversal form of the same tree
     const GpuTri* stris;            // triangles in leaf order; `pad` holds the original triangle id
     uint32_t n_wnodes;
-    const GpuSahNode* xnodes;       // closest-hit hierarchy (surface-area heuristic, FP32 boxes)
+    const GpuQuadNode* xnodes;      // closest-hit hierarchy (surface-area heuristic, four children, FP32 boxes)
     const GpuTri* xtris;            // its triangles in its own leaf order; `pad` = position in `stris`
     uint32_t n_xnodes;
     const GpuTriAux* aux;

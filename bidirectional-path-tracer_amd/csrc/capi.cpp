@@ -182,7 +182,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const size_t vslots = 2 * (size_t)(depth > 0 ? depth : 1);
     const uint32_t vis_words = (uint32_t)((depth > 0 ? depth : 1) + 63) / 64;
     const size_t shadow_per_slot = (size_t)(depth > 0 ? depth : 1);
-    if ((int)scene->host.tree_depth > kWideStackDepth || (int)scene->host.sah_depth > kWideStackDepth)
+    if ((int)scene->host.tree_depth > kWideStackDepth || (int)scene->host.sah_stack + 3 > kQuadStackEntries)
         return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     if (n_owned >= ((int64_t)1 << 31)) return fail(BDPT_ERR_UNSUPPORTED, "more than 2^31 pixels in one call");
     // bytes of state per sample slot
@@ -240,7 +240,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     WfLaunchCfg cfg;
     {   // per traversal kernel: its own node table + its own triangle order
         const size_t shadow_bytes = (size_t)scene->dev.n_wnodes * sizeof(GpuWideNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
-        const size_t extend_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuSahNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
+        const size_t extend_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuQuadNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
         cfg.lds_bytes = shadow_bytes > extend_bytes ? shadow_bytes : extend_bytes;
     }
     cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
@@ -251,7 +251,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         int kb = env_int("BDPT_WF_LDS_KB", 32);
         if (kb < 1) kb = 1;
         if (kb > 128) kb = 128;
-        cfg.top_nodes = (uint32_t)kb * 1024u / (uint32_t)sizeof(GpuSahNode);
+        cfg.top_nodes = (uint32_t)kb * 1024u / 128u;
     }
     int per_cu = 1;
     HIP_TRY(wf_prepare_traverse(cfg, &per_cu));
@@ -262,16 +262,6 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     cfg.leaf_threshold = env_int("BDPT_WF_LEAF", 24);
     cfg.chunk = (uint32_t)env_int("BDPT_WF_CHUNK", 128);
     cfg.stream_blocks = ctx->cu_count * 8;
-    const bool staged = env_int("BDPT_WF_STAGED", 1) != 0;      // one kernel per bounce and stage instead of the fused subpath kernel
-    {
-        int paths_per_cu = 1;
-        cfg.paths_waves = env_int("BDPT_WF_PATHS_WAVES", 4);
-        if (cfg.paths_waves < 2 || cfg.paths_waves > 4) cfg.paths_waves = 4;
-        HIP_TRY(wf_paths_blocks_per_cu(cfg.lds_scene, cfg.lds_bytes, cfg.paths_waves, &paths_per_cu));
-        paths_per_cu = env_int("BDPT_WF_PATHS_BLOCKS_PER_CU", paths_per_cu);
-        cfg.paths_blocks = ctx->cu_count * paths_per_cu;
-        cfg.shade_threshold = env_int("BDPT_WF_SHADE_THRESHOLD", 24);
-    }
 
     const GpuCamera gcam = to_gpu_camera(*cam);
     unsigned long long* stats = stats_mode ? ctx->stats : nullptr;
@@ -324,32 +314,27 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         const uint32_t n_slots = (uint32_t)((int64_t)b.n_pixels * spp);
 
         HIP_TRY(hipMemsetAsync(C, 0, n_counters * 4, st));
-        if (!staged) {
-            // both subpaths of every sample: camera.h:300-313
-            HIP_TRY(wf_paths(scene->dev, gcam, wb, b, n_slots, eye_cursor(0), cfg, stats, st));
-        } else {
-            HIP_TRY(wf_gen_eye(scene->dev, gcam, wb, b, cfg, st));
-            // eye subpath: camera.h:303 -> trace_path(r, depth, ...)
-            int cur = 0;
-            for (int k = 0; k < depth; k++) {
-                const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
-                const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
-                { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
-                const int nxt = (k == 0) ? 0 : (cur ^ 1);
-                HIP_TRY(wf_shade(scene->dev, gcam, wb, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, cfg,
-                                 stats, st));
-                cur = nxt;
-            }
-            // light subpath: camera.h:313 -> build_light_path -> trace_path(light_ray, depth - 1, ...)
-            if (depth > 0) {
-                HIP_TRY(wf_gen_light(scene->dev, gcam, wb, b, wb.queue[0], light_count(0), cfg, stats, st));
-                cur = 0;
-                for (int k = 0; k < depth - 1; k++) {
-                    { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
-                    HIP_TRY(wf_shade(scene->dev, gcam, wb, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
-                                     light_count(k + 1), k == depth - 2, cfg, stats, st));
-                    cur ^= 1;
-                }
+        HIP_TRY(wf_gen_eye(scene->dev, gcam, wb, b, cfg, st));
+        // eye subpath: camera.h:303 -> trace_path(r, depth, ...)
+        int cur = 0;
+        for (int k = 0; k < depth; k++) {
+            const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
+            const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
+            { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
+            const int nxt = (k == 0) ? 0 : (cur ^ 1);
+            HIP_TRY(wf_shade(scene->dev, gcam, wb, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, cfg,
+                             stats, st));
+            cur = nxt;
+        }
+        // light subpath: camera.h:313 -> build_light_path -> trace_path(light_ray, depth - 1, ...)
+        if (depth > 0) {
+            HIP_TRY(wf_gen_light(scene->dev, gcam, wb, b, wb.queue[0], light_count(0), cfg, stats, st));
+            cur = 0;
+            for (int k = 0; k < depth - 1; k++) {
+                { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
+                HIP_TRY(wf_shade(scene->dev, gcam, wb, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
+                                 light_count(k + 1), k == depth - 2, cfg, stats, st));
+                cur ^= 1;
             }
         }
         // connections: camera.h:316-320
@@ -512,7 +497,7 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     size_t off_wn = off_tris + align256(h.tris.size() * sizeof(GpuTri));
     size_t off_st = off_wn + align256(h.wnodes.size() * sizeof(GpuWideNode));
     size_t off_xn = off_st + align256(h.stris.size() * sizeof(GpuTri));
-    size_t off_xt = off_xn + align256(h.xnodes.size() * sizeof(GpuSahNode));
+    size_t off_xt = off_xn + align256(h.xnodes.size() * sizeof(GpuQuadNode));
     size_t off_aux = off_xt + align256(h.xtris.size() * sizeof(GpuTri));
     size_t off_mats = off_aux + align256(h.aux.size() * sizeof(GpuTriAux));
     size_t off_ltri = off_mats + align256(h.mats.size() * sizeof(GpuMaterial));
@@ -528,7 +513,7 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
         {off_tris, h.tris.data(), h.tris.size() * sizeof(GpuTri)},
         {off_wn, h.wnodes.data(), h.wnodes.size() * sizeof(GpuWideNode)},
         {off_st, h.stris.data(), h.stris.size() * sizeof(GpuTri)},
-        {off_xn, h.xnodes.data(), h.xnodes.size() * sizeof(GpuSahNode)},
+        {off_xn, h.xnodes.data(), h.xnodes.size() * sizeof(GpuQuadNode)},
         {off_xt, h.xtris.data(), h.xtris.size() * sizeof(GpuTri)},
         {off_aux, h.aux.data(), h.aux.size() * sizeof(GpuTriAux)},
         {off_mats, h.mats.data(), h.mats.size() * sizeof(GpuMaterial)},
@@ -545,7 +530,7 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     d.wnodes = reinterpret_cast<const GpuWideNode*>(base + off_wn);
     d.stris = reinterpret_cast<const GpuTri*>(base + off_st);
     d.n_wnodes = (uint32_t)h.wnodes.size();
-    d.xnodes = reinterpret_cast<const GpuSahNode*>(base + off_xn);
+    d.xnodes = reinterpret_cast<const GpuQuadNode*>(base + off_xn);
     d.xtris = reinterpret_cast<const GpuTri*>(base + off_xt);
     d.n_xnodes = (uint32_t)h.xnodes.size();
     d.aux = reinterpret_cast<const GpuTriAux*>(base + off_aux);

@@ -95,6 +95,8 @@ inline double vx(const double* v, int k) { return v[k]; }
 // ---------------------------------------------------------------------------------------------
 // Binned surface-area-heuristic hierarchy for closest-hit queries.
 struct SahRef { double lo[3], hi[3], c[3]; uint32_t pos; };
+// binary record of the builder: both child boxes (FP32, rounded outward) and child references
+struct SahBinNode { float lo0[3], hi0[3], lo1[3], hi1[3]; int32_t child0, child1; };
 
 inline float round_down(double x) {
     float f = (float)x;
@@ -109,7 +111,7 @@ inline float round_up(double x) {
 
 struct SahBuilder {
     std::vector<SahRef> refs;
-    std::vector<GpuSahNode> nodes;
+    std::vector<SahBinNode> nodes;
     std::vector<uint32_t> leaf_order;      // positions (in stris) in this hierarchy's leaf order
     uint32_t max_depth = 0;
 
@@ -198,27 +200,27 @@ struct SahBuilder {
             if (mid == a || mid == b) mid = a + n / 2;
         }
         const int32_t idx = (int32_t)nodes.size();
-        nodes.push_back(GpuSahNode());
+        nodes.push_back(SahBinNode());
         double lo0[3], hi0[3], lo1[3], hi1[3];
         bounds(a, mid, lo0, hi0);
         bounds(mid, b, lo1, hi1);
         const int32_t c0r = build(a, mid, depth + 1);
         const int32_t c1r = build(mid, b, depth + 1);
-        GpuSahNode& nd = nodes[idx];
+        SahBinNode& nd = nodes[idx];
         for (int k = 0; k < 3; k++) {
             nd.lo0[k] = round_down(lo0[k]); nd.hi0[k] = round_up(hi0[k]);
             nd.lo1[k] = round_down(lo1[k]); nd.hi1[k] = round_up(hi1[k]);
         }
         nd.child0 = c0r; nd.child1 = c1r;
-        nd.pad[0] = nd.pad[1] = 0;
         return idx;
     }
 };
 
 // Puts the `top` records nearest the root first (breadth-first), the rest in their previous order,
 // and rewrites the interior child references.  The traversal kernels keep that prefix in LDS.
-template <class NodeT>
-void hoist_top_levels(std::vector<NodeT>& nodes, size_t top) {
+// `kids(node)` returns a pointer to the record's child references, N of them.
+template <int N, class NodeT, class Kids>
+void hoist_top_levels(std::vector<NodeT>& nodes, size_t top, Kids kids) {
     const size_t n = nodes.size();
     if (n <= 2 || top <= 1) return;
     std::vector<int32_t> order;
@@ -227,10 +229,9 @@ void hoist_top_levels(std::vector<NodeT>& nodes, size_t top) {
     order.push_back(0);
     taken[0] = 1;
     for (size_t head = 0; head < order.size() && order.size() < top; head++) {
-        const NodeT& nd = nodes[order[head]];
-        const int32_t kids[2] = {nd.child0, nd.child1};
-        for (int32_t c : kids)
-            if (c >= 0 && !taken[c] && order.size() < top) { order.push_back(c); taken[c] = 1; }
+        const int32_t* c = kids(nodes[order[head]]);
+        for (int k = 0; k < N; k++)
+            if (c[k] >= 0 && !taken[c[k]] && order.size() < top) { order.push_back(c[k]); taken[c[k]] = 1; }
     }
     for (size_t i = 0; i < n; i++) if (!taken[i]) order.push_back((int32_t)i);
     std::vector<int32_t> new_index(n);
@@ -238,12 +239,64 @@ void hoist_top_levels(std::vector<NodeT>& nodes, size_t top) {
     std::vector<NodeT> out(n);
     for (size_t k = 0; k < n; k++) {
         NodeT nd = nodes[order[k]];
-        if (nd.child0 >= 0) nd.child0 = new_index[nd.child0];
-        if (nd.child1 >= 0) nd.child1 = new_index[nd.child1];
+        int32_t* c = kids(nd);
+        for (int q = 0; q < N; q++) if (c[q] >= 0) c[q] = new_index[c[q]];
         out[k] = nd;
     }
     nodes.swap(out);
 }
+
+// Collapses the binary surface-area tree to four children per record: starting from a record's two
+// children, the interior child with the largest box is replaced by its own two children until there
+// are four (or only leaves are left).  `stack_need` becomes the most entries a depth-first walk that
+// pushes every child but the one it enters can have on its stack.
+struct QuadCollapse {
+    const std::vector<SahBinNode>& bin;
+    std::vector<GpuQuadNode> out;
+    uint32_t stack_need = 0;
+    struct Kid { float lo[3], hi[3]; int32_t ref; };
+    static double area(const Kid& k) {
+        const double dx = (double)k.hi[0] - k.lo[0], dy = (double)k.hi[1] - k.lo[1], dz = (double)k.hi[2] - k.lo[2];
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+    static void kids_of(const SahBinNode& b, Kid& k0, Kid& k1) {
+        for (int a = 0; a < 3; a++) { k0.lo[a] = b.lo0[a]; k0.hi[a] = b.hi0[a]; k1.lo[a] = b.lo1[a]; k1.hi[a] = b.hi1[a]; }
+        k0.ref = b.child0; k1.ref = b.child1;
+    }
+    explicit QuadCollapse(const std::vector<SahBinNode>& b) : bin(b) {}
+    int32_t collapse(int32_t bin_index, uint32_t stack_above) {
+        Kid kid[4];
+        int n = 2;
+        kids_of(bin[bin_index], kid[0], kid[1]);
+        while (n < 4) {
+            int pick = -1;
+            double best = -1.0;
+            for (int k = 0; k < n; k++)
+                if (kid[k].ref >= 0 && area(kid[k]) > best) { best = area(kid[k]); pick = k; }
+            if (pick < 0) break;
+            Kid a, b2;
+            kids_of(bin[kid[pick].ref], a, b2);
+            kid[pick] = a;
+            kid[n++] = b2;
+        }
+        const int32_t idx = (int32_t)out.size();
+        out.push_back(GpuQuadNode());
+        const uint32_t below = stack_above + (uint32_t)(n - 1);
+        if (below > stack_need) stack_need = below;
+        int32_t refs[4];
+        for (int k = 0; k < n; k++) refs[k] = kid[k].ref >= 0 ? collapse(kid[k].ref, below) : kid[k].ref;
+        GpuQuadNode& q = out[idx];
+        for (int k = 0; k < 4; k++) {
+            for (int a = 0; a < 3; a++) {
+                q.lo[k][a] = k < n ? kid[k].lo[a] : std::numeric_limits<float>::infinity();
+                q.hi[k][a] = k < n ? kid[k].hi[a] : -std::numeric_limits<float>::infinity();
+            }
+            q.child[k] = k < n ? refs[k] : kQuadEmpty;
+            q.pad[k] = 0;
+        }
+        return idx;
+    }
+};
 
 }  // namespace
 
@@ -385,7 +438,7 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
         }
     }
 
-    hoist_top_levels(out.wnodes, kLdsTopWideNodes);
+    hoist_top_levels<2>(out.wnodes, kLdsTopWideNodes, [](GpuWideNode& w) { return &w.child0; });
 
     // closest-hit hierarchy over the same triangles (referenced by their position in `stris`)
     {
@@ -408,7 +461,7 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
         sb.leaf_order.reserve(out.stris.size());
         int32_t root = sb.build(0, sb.refs.size(), 1);
         if (root < 0) {                        // one leaf only: wrap it so that record 0 exists
-            GpuSahNode w{};
+            SahBinNode w{};
             double lo[3], hi[3];
             sb.bounds(0, sb.refs.size(), lo, hi);
             for (int k = 0; k < 3; k++) {
@@ -416,12 +469,14 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
                 w.lo1[k] = std::numeric_limits<float>::infinity(); w.hi1[k] = -std::numeric_limits<float>::infinity();
             }
             w.child0 = root;
-            w.child1 = ~(int32_t)0;
+            w.child1 = kQuadEmpty;
             sb.nodes.push_back(w);
         }
-        hoist_top_levels(sb.nodes, kLdsTopSahNodes);
-        out.xnodes = sb.nodes;
-        out.sah_depth = sb.max_depth;
+        QuadCollapse qc(sb.nodes);
+        qc.collapse(0, 0);
+        hoist_top_levels<4>(qc.out, kLdsTopQuadNodes, [](GpuQuadNode& q) { return &q.child[0]; });
+        out.xnodes.swap(qc.out);
+        out.sah_stack = qc.stack_need;
         out.xtris.resize(sb.leaf_order.size());
         for (size_t k = 0; k < sb.leaf_order.size(); k++) {
             GpuTri t = out.stris[sb.leaf_order[k]];

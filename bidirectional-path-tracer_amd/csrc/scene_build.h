@@ -17,9 +17,9 @@ struct HostScene {
     std::vector<GpuTri> tris;
     std::vector<GpuWideNode> wnodes;     // interior nodes in pre-order, both child boxes per record
     std::vector<GpuTri> stris;           // triangles in leaf order (pad = original id)
-    std::vector<GpuSahNode> xnodes;      // closest-hit hierarchy (binned SAH)
+    std::vector<GpuQuadNode> xnodes;     // closest-hit hierarchy (binned SAH, four children per record)
     std::vector<GpuTri> xtris;           // its triangles in leaf order (pad = position in stris)
-    uint32_t sah_depth = 0;
+    uint32_t sah_stack = 0;              // most entries its traversal stack can hold at once
     std::vector<GpuTriAux> aux;
     std::vector<GpuMaterial> mats;
     std::vector<uint32_t> light_tris;

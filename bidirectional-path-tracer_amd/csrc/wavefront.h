@@ -34,6 +34,8 @@ struct WfBuffers {
 
 // per-lane stack of the ordered walk (one entry per tree level at most)
 constexpr int kWideStackDepth = 40;
+// entries of the closest-hit walk's stack (up to three pushes per level of the four-wide tree)
+constexpr int kQuadStackEntries = 64;
 
 constexpr uint32_t kCntEyeHit = 1u << 24, kCntLightHit = 1u << 25, kCntLightValid = 1u << 26;
 
@@ -56,20 +58,12 @@ struct WfLaunchCfg {
     int leaf_threshold;       // lanes of a wave that must stand at a leaf before the wave turns to triangle tests
     uint32_t chunk;           // ray indices a wave takes from the global cursor at a time
     int trav_block;           // threads per traversal workgroup when the scene does not fit LDS (256, 512 or 1024)
-    uint32_t top_nodes;       // 64-byte records of the top tree levels each such workgroup keeps in LDS
-    int paths_blocks;         // grid of the fused subpath kernel
-    int paths_waves;          // its register budget: waves per SIMD it is compiled for (2, 3 or 4)
-    int shade_threshold;      // its lanes shade together once this many of a wave have a finished ray
+    uint32_t top_nodes;       // 128-byte records of the top tree levels each such workgroup keeps in LDS
 };
 
 // counts of the work done, accumulated by the kernels when `stats` is non-null (bdpt_stats order)
 hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const WfLaunchCfg& cfg,
                       hipStream_t st);
-// eye and light subpath of every sample of the batch in one persistent kernel (replaces gen_eye, the
-// extend / shade pairs and gen_light)
-hipError_t wf_paths(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t n_slots,
-                    uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
-hipError_t wf_paths_blocks_per_cu(bool lds_scene, size_t lds_bytes, int waves, int* out);
 hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                      uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,

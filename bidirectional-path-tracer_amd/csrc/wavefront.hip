@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb,
 //  * the root's own box (bvh.h:52 at the root) is not tested separately: it contains both child
 //    boxes, and the slab arithmetic is monotone, so a ray that passes a child box passes the root box.
 constexpr int kStackDepth = kWideStackDepth;
-constexpr size_t kTopLdsBytes = 32 * 1024;   // LDS copy of the top levels in the fused subpath kernel
+constexpr int kQuadStackDepth = kQuadStackEntries;
 constexpr int32_t kPop = (int32_t)0x80000000;   // neither an interior index (>= 0) nor a leaf reference
 
 template <class NodeT>
@@ -193,6 +193,25 @@ BDPT_DEV void slab(const T* blo, const T* bhi, V3 o, double ix, double iy, doubl
     }
 }
 
+// A child the ray enters, as one 64-bit word that orders like its entry distance: high half = the bits
+// of the distance as a positive FP32 number rounded DOWN (so culling against it later stays
+// conservative), low half = the child reference.  Read as an FP64 number the word is positive and
+// finite, and larger distance <=> larger number, so a compare-exchange is one min and one max
+// instruction.  Children the ray misses get +infinity and sort last.
+BDPT_DEV double quad_entry(bool in, double lo, int32_t child) {
+    float f = (float)lo;                                   // lo >= 0.001 > 0
+    uint32_t bits = __float_as_uint(f);
+    if ((double)f > lo) bits -= 1u;                        // next FP32 number towards zero
+    if (!in) bits = 0x7F800000u;
+    return __longlong_as_double((long long)(((unsigned long long)bits << 32) | (uint32_t)child));
+}
+BDPT_DEV int32_t quad_entry_child(double e) { return (int32_t)(uint32_t)(unsigned long long)__double_as_longlong(e); }
+BDPT_DEV float quad_entry_near(double e) { return __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(e) >> 32)); }
+BDPT_DEV void sort2(double& a, double& b) {
+    const double lo = __builtin_fmin(a, b), hi = __builtin_fmax(a, b);
+    a = lo; b = hi;
+}
+
 // One loop iteration is EITHER one interior record for every lane that stands at one, OR one triangle
 // for every lane that stands at a leaf: a wave executes both sides of a divergent branch one after the
 // other, so mixing the two in one iteration would run the (long) triangle test for a handful of lanes
@@ -208,8 +227,10 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
     int32_t cur = kPop;                 // interior record to visit next (when leaf_left == 0)
     uint32_t leaf_next = 0, leaf_left = 0;   // triangles of the current leaf still to test
     int sp = 0;
-    int32_t stk_node[kStackDepth];
-    double stk_lo[kStackDepth];
+    // SHADOW: (record, entry distance) pairs; closest hit: one 64-bit word per entry, see quad_entry()
+    int32_t stk_node[SHADOW ? kStackDepth : 1];
+    double stk_lo[SHADOW ? kStackDepth : 1];
+    double stk_quad[SHADOW ? 1 : kQuadStackDepth];
     unsigned long long tag = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     double ix = 0, iy = 0, iz = 0, closest = 0;
@@ -278,20 +299,42 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
             if (has && leaf_left == 0) {
                 const auto nd = mem.wnode(cur);
                 if (STATS) n_records++;
-                double lo0, hi0, lo1, hi1;
-                slab(nd.lo0, nd.hi0, o, ix, iy, iz, closest, lo0, hi0);
-                slab(nd.lo1, nd.hi1, o, ix, iy, iz, closest, lo1, hi1);
-                const bool p0 = !(hi0 <= lo0), p1 = !(hi1 <= lo1);
-                if (STATS) n_box_hits += (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
-                if (p0 && p1) {
-                    const bool second_first = lo1 < lo0;
-                    stk_node[sp] = second_first ? nd.child0 : nd.child1;    // sp < tree depth <= kStackDepth (checked by the host)
-                    stk_lo[sp] = second_first ? lo0 : lo1;
-                    sp++;
-                    cur = second_first ? nd.child1 : nd.child0;
-                } else if (p0) cur = nd.child0;
-                else if (p1) cur = nd.child1;
-                else pop = true;
+                if constexpr (SHADOW) {
+                    double lo0, hi0, lo1, hi1;
+                    slab(nd.lo0, nd.hi0, o, ix, iy, iz, closest, lo0, hi0);
+                    slab(nd.lo1, nd.hi1, o, ix, iy, iz, closest, lo1, hi1);
+                    const bool p0 = !(hi0 <= lo0), p1 = !(hi1 <= lo1);
+                    if (STATS) n_box_hits += (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
+                    if (p0 && p1) {
+                        const bool second_first = lo1 < lo0;
+                        stk_node[sp] = second_first ? nd.child0 : nd.child1;    // sp < tree depth <= kStackDepth (checked by the host)
+                        stk_lo[sp] = second_first ? lo0 : lo1;
+                        sp++;
+                        cur = second_first ? nd.child1 : nd.child0;
+                    } else if (p0) cur = nd.child0;
+                    else if (p1) cur = nd.child1;
+                    else pop = true;
+                } else {
+                    // four children: sort the ones the ray enters by entry distance, go to the nearest, push the rest
+                    double e[4];
+                    int n_in = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        double lo, hi;
+                        slab(nd.lo[k], nd.hi[k], o, ix, iy, iz, closest, lo, hi);
+                        const bool in = (nd.child[k] != kQuadEmpty) && !(hi <= lo);
+                        e[k] = quad_entry(in, lo, nd.child[k]);
+                        n_in += in ? 1 : 0;
+                    }
+                    if (STATS) n_box_hits += (uint32_t)n_in;
+                    sort2(e[0], e[1]); sort2(e[2], e[3]); sort2(e[0], e[2]); sort2(e[1], e[3]); sort2(e[1], e[2]);
+                    // sp + 3 <= kQuadStackDepth: the host checks the worst case of the tree
+                    if (n_in > 3) stk_quad[sp++] = e[3];
+                    if (n_in > 2) stk_quad[sp++] = e[2];
+                    if (n_in > 1) stk_quad[sp++] = e[1];
+                    if (n_in > 0) cur = quad_entry_child(e[0]);
+                    else pop = true;
+                }
             }
         } else {
             if (has && leaf_left > 0) {
@@ -317,9 +360,14 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
             done = true;
             while (sp > 0) {
                 sp--;
-                const double e_lo = stk_lo[sp];
-                const int32_t e_node = stk_node[sp];
-                if (!(closest <= e_lo)) { cur = e_node; done = false; break; }    // aabb.h:61 with the current bound
+                if constexpr (SHADOW) {
+                    const double e_lo = stk_lo[sp];
+                    const int32_t e_node = stk_node[sp];
+                    if (!(closest <= e_lo)) { cur = e_node; done = false; break; }    // aabb.h:61 with the current bound
+                } else {
+                    const double e = stk_quad[sp];
+                    if (!(closest <= (double)quad_entry_near(e))) { cur = quad_entry_child(e); done = false; break; }
+                }
             }
         }
         if (has && !done && leaf_left == 0 && cur < 0) {      // arrived at a leaf: ~cur = (first << 2) | (count - 1)
@@ -344,9 +392,9 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
     }
     if (STATS) {
         flush_wave_counter(&stats[SHADOW ? 6 : 0], n_rays);
-        flush_wave_counter(&stats[1], 2ull * n_records);
+        flush_wave_counter(&stats[1], (SHADOW ? 2ull : 4ull) * n_records);
         flush_wave_counter(&stats[2], n_box_hits);
-        flush_wave_counter(&stats[3], (SHADOW ? 2ull : 1ull) * n_records);   // in units of 64 bytes fetched
+        flush_wave_counter(&stats[3], 2ull * n_records);   // in units of 64 bytes fetched (both record types are 128 bytes)
         flush_wave_counter(&stats[4], n_tri);
         flush_wave_counter(&stats[5], n_tri_hits);
     }
@@ -376,7 +424,7 @@ BDPT_DEV void stage_tree(const NodeT* nodes, uint32_t n_nodes, const GpuTri* tri
 }
 
 // SHADOW walks the reference's own tree (GpuWideNode): whether a visibility query is blocked depends on
-// that tree's boxes.  Closest-hit queries walk the surface-area-heuristic hierarchy (GpuSahNode).
+// that tree's boxes.  Closest-hit queries walk the surface-area-heuristic hierarchy (GpuQuadNode).
 template <bool SHADOW, bool STATS, bool LDS_SCENE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
                                                     const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
@@ -393,254 +441,25 @@ __global__ __launch_bounds__(BLOCK) void k_traverse(SceneDev sc, WfBuffers wb, c
             traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold);
         } else {
             GpuWideNode* l_nodes = reinterpret_cast<GpuWideNode*>(smem);
-            const uint32_t n_top = sc.n_wnodes < top_nodes / 2 ? sc.n_wnodes : top_nodes / 2;      // 128-byte records
+            const uint32_t n_top = sc.n_wnodes < top_nodes ? sc.n_wnodes : top_nodes;
             stage_tree(sc.wnodes, n_top, sc.stris, 0u, l_nodes, (GpuTri*)nullptr);
             TopLdsMem<GpuWideNode> mem{l_nodes, sc.wnodes, sc.stris, (int32_t)n_top};
             traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold);
         }
     } else {
         if (LDS_SCENE) {
-            GpuSahNode* l_nodes = reinterpret_cast<GpuSahNode*>(smem);
+            GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
             stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
-            TreeMem<GpuSahNode> mem{l_nodes, l_tris};
+            TreeMem<GpuQuadNode> mem{l_nodes, l_tris};
             traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold);
         } else {
-            GpuSahNode* l_nodes = reinterpret_cast<GpuSahNode*>(smem);
+            GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
             stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
-            TopLdsMem<GpuSahNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
+            TopLdsMem<GpuQuadNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
             traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold);
         }
-    }
-}
-
-// ------------------------------------------------------------------ both subpaths of a sample in one persistent kernel
-// A lane owns one sample from its camera ray to the end of its light subpath (camera.h:300-313): it
-// walks the closest-hit hierarchy for the current ray, waits until enough lanes of its wave have a
-// finished ray, shades together with them (vertex, emission, next ray; at the end of the eye subpath
-// the emitter sample and the first light ray), and takes the next sample from the batch cursor when
-// its own is complete.  No ray state goes through memory and no bounce waits for the slowest ray of
-// the batch.  The order of the operations of ONE sample - and so every random draw and every rounding -
-// is that of sample_radiance() up to the connection loop; what a sample leaves behind (stored
-// vertices, counts, the unconnected radiance) is what the connection kernels below read.
-constexpr int kLaneIdle = 0, kLaneWalk = 1, kLaneShade = 2;
-
-template <bool STATS, class Mem>
-BDPT_DEV void paths_loop(const Mem& mem, const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b,
-                         uint32_t n_slots, uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold,
-                         const uint32_t kChunk, const int kShadeThreshold) {
-    const int depth = cam.max_depth;
-    const uint64_t ns = wb.ns;
-    int state = kLaneIdle;
-    uint32_t slot = 0;
-    bool eye = true;
-    int remaining = 0;                 // bounces left in the current subpath
-    uint32_t cnt = 0;                  // stored-vertex counts and flags, layout of WfBuffers::counts
-    Rng rng;
-    rng.key = 0; rng.counter = 0;
-    V3 T = mk(0, 0, 0);
-    // traversal state
-    int32_t cur = kPop;
-    int sp = 0;
-    int32_t stk_node[kStackDepth];
-    double stk_lo[kStackDepth];
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
-    double ix = 0, iy = 0, iz = 0, closest = 0;
-    HitLite h;
-    h.t = 0; h.u = 0; h.v = 0; h.tri = -1;
-    int32_t best_pos = -1;
-    uint32_t pool_next = 0, pool_end = 0;     // wave-uniform
-    bool exhausted = (n_slots == 0);
-    uint32_t n_records = 0, n_box_hits = 0, n_tri = 0, n_tri_hits = 0, n_rays = 0, n_stored = 0;
-
-    auto start_ray = [&]() {
-        ix = 1.0 / d.x; iy = 1.0 / d.y; iz = 1.0 / d.z;       // aabb.h:48, once per ray
-        closest = kInf;
-        cur = 0; sp = 0;
-        h.tri = -1; best_pos = -1;
-        state = kLaneWalk;
-        if (STATS) n_rays++;
-    };
-
-    for (;;) {
-        // ---- new samples for idle lanes
-        const unsigned long long idle = __ballot(state == kLaneIdle);
-        const int n_idle = __builtin_popcountll(idle);
-        if (!exhausted && n_idle >= kRefillThreshold) {
-            if (pool_next == pool_end) {
-                uint32_t base = 0;
-                if (lane_id() == 0) base = atomicAdd(cursor, kChunk);
-                base = __shfl(base, 0, 64);
-                if (base >= n_slots) { exhausted = true; pool_next = pool_end = 0; }
-                else { pool_next = base; pool_end = (base + kChunk < n_slots) ? base + kChunk : n_slots; }
-            }
-            const uint32_t avail = pool_end - pool_next;
-            const uint32_t give = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
-            if (state == kLaneIdle) {
-                const uint32_t r = rank_in_mask(idle);
-                if (r < give) {
-                    slot = pool_next + r;
-                    int pi, pj, ps;
-                    if (slot_to_sample(cam, b, slot, pi, pj, ps)) {
-                        rng.key = stream_key(b.seed, (uint64_t)pj * (uint64_t)cam.width + (uint64_t)pi, (uint64_t)ps);
-                        rng.counter = 0;
-                        const int s_j = ps / cam.sqrt_spp, s_i = ps - s_j * cam.sqrt_spp;
-                        camera_ray(cam, pi, pj, s_i, s_j, rng, o, d);
-                        T = mk(1.0, 1.0, 1.0);
-                        eye = true;
-                        remaining = depth;
-                        cnt = 0;
-                        if (depth > 0) start_ray();
-                        else { h.tri = -1; state = kLaneShade; remaining = 0; }    // no bounce at all: straight to the subpath end
-                    } else {
-                        wb.counts[slot] = 0; wb.ctr[slot] = 0;
-                        wb.result[slot] = 0.0; wb.result[ns + slot] = 0.0; wb.result[2 * ns + slot] = 0.0;
-                    }
-                }
-            }
-            pool_next += give;
-        }
-        const unsigned long long walking = __ballot(state == kLaneWalk);
-        const unsigned long long pending = __ballot(state == kLaneShade);
-        if ((walking | pending) == 0) {
-            if (exhausted) break;
-            continue;
-        }
-        // ---- shading, once enough lanes wait for it (or nobody is walking)
-        if (pending && (__builtin_popcountll(pending) >= kShadeThreshold || walking == 0)) {
-            if (state == kLaneShade) {
-                bool subpath_ends = true;
-                V3 radiance = mk(0, 0, 0);          // eye subpath: background or emission term, written when it ends
-                if (remaining > 0) {
-                    if (h.tri < 0) {
-                        // camera.h:337-338: background_contrib (0) += throughput * background
-                        if (eye) radiance = add(mk(0, 0, 0), mulv(T, ld3(cam.background)));
-                    } else {
-                        HitLite hh = h;
-                        hh.tri = sc.stris[h.tri].pad;            // leaf position -> triangle id
-                        Bounce bo;
-                        shade_bounce<true>(sc, o, d, hh, T, rng, bo);
-                        cnt |= eye ? kCntEyeHit : kCntLightHit;
-                        if (bo.keep) {
-                            const uint32_t ne = cnt & 0xFFFu, nl = (cnt >> 12) & 0xFFFu;
-                            slot_store(wb, slot).put(eye ? (int)ne : depth + (int)nl, bo.vx);
-                            cnt += eye ? 1u : (1u << 12);
-                            if (STATS) n_stored++;
-                        }
-                        // result = background_contrib (0) + throughput * emission, camera.h:306-309
-                        if (eye && bo.emitted) radiance = add(mk(0, 0, 0), bo.emitted_term);
-                        remaining--;
-                        if (bo.cont && remaining > 0) {
-                            o = bo.o; d = bo.d; T = bo.T;
-                            start_ray();
-                            subpath_ends = false;
-                        }
-                    }
-                }
-                if (subpath_ends) {
-                    bool finished = true;
-                    if (eye) {
-                        wb.result[slot] = radiance.x; wb.result[ns + slot] = radiance.y; wb.result[2 * ns + slot] = radiance.z;
-                        // light subpath: camera.h:313 -> build_light_path -> trace_path(light_ray, depth - 1, ...)
-                        Emitter em;
-                        sample_emitter(sc, depth, rng, em);
-                        if (em.valid) {
-                            slot_store(wb, slot).put(depth, em.ev);
-                            if (STATS) n_stored++;
-                            cnt |= kCntLightValid | kCntLightHit | (1u << 12);
-                            if (em.has_ray && depth - 1 > 0) {
-                                o = em.o; d = em.d; T = em.T;
-                                eye = false;
-                                remaining = depth - 1;
-                                start_ray();
-                                finished = false;
-                            }
-                        }
-                    }
-                    if (finished) {
-                        wb.counts[slot] = cnt;
-                        wb.ctr[slot] = rng.counter;
-                        state = kLaneIdle;
-                    }
-                }
-            }
-            continue;      // refill / re-evaluate before the next walk step
-        }
-        // ---- one record (or leaf) of the ordered walk, see traverse_queue
-        if (state == kLaneWalk) {
-            if (cur >= 0) {
-                const auto nd = mem.wnode(cur);
-                if (STATS) n_records++;
-                double lo0, hi0, lo1, hi1;
-                slab(nd.lo0, nd.hi0, o, ix, iy, iz, closest, lo0, hi0);
-                slab(nd.lo1, nd.hi1, o, ix, iy, iz, closest, lo1, hi1);
-                const bool p0 = !(hi0 <= lo0), p1 = !(hi1 <= lo1);
-                if (STATS) n_box_hits += (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
-                if (p0 && p1) {
-                    const bool second_first = lo1 < lo0;
-                    stk_node[sp] = second_first ? nd.child0 : nd.child1;
-                    stk_lo[sp] = second_first ? lo0 : lo1;
-                    sp++;
-                    cur = second_first ? nd.child1 : nd.child0;
-                } else if (p0) cur = nd.child0;
-                else if (p1) cur = nd.child1;
-                else cur = kPop;
-            } else {
-                const uint32_t code = (uint32_t)~cur;
-                const uint32_t first = code >> 2;
-                const uint32_t n_here = 1u + (code & 3u);
-                for (uint32_t q = 0; q < n_here; q++) {
-                    const GpuTri tr = mem.stri(first + q);
-                    double t, u, v;
-                    const bool inside = tri_test(tr, o, d, 0.001, closest, t, u, v);
-                    if (STATS) { n_tri++; if (inside) n_tri_hits++; }
-                    if (inside && (t < closest || best_pos < 0 || tr.pad > best_pos)) {
-                        closest = t; h.t = t; h.u = u; h.v = v; best_pos = tr.pad; h.tri = tr.pad;
-                    }
-                }
-                cur = kPop;
-            }
-            if (cur == kPop) {
-                bool done = true;
-                while (sp > 0) {
-                    sp--;
-                    const double e_lo = stk_lo[sp];
-                    const int32_t e_node = stk_node[sp];
-                    if (!(closest <= e_lo)) { cur = e_node; done = false; break; }
-                }
-                if (done) state = kLaneShade;
-            }
-        }
-    }
-    if (STATS) {
-        flush_wave_counter(&stats[0], n_rays);
-        flush_wave_counter(&stats[1], 2ull * n_records);
-        flush_wave_counter(&stats[2], n_box_hits);
-        flush_wave_counter(&stats[3], n_records);            // in units of 64 bytes fetched
-        flush_wave_counter(&stats[4], n_tri);
-        flush_wave_counter(&stats[5], n_tri_hits);
-        flush_wave_counter(&stats[10], n_stored);
-    }
-}
-
-template <bool STATS, bool LDS_SCENE, int WAVES>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_paths(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, uint32_t n_slots,
-                                                  uint32_t* cursor, unsigned long long* stats, int refill_threshold,
-                                                  uint32_t chunk, int shade_threshold) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    GpuSahNode* l_nodes = reinterpret_cast<GpuSahNode*>(smem);
-    if (LDS_SCENE) {
-        GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
-        stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
-        TreeMem<GpuSahNode> mem{l_nodes, l_tris};
-        paths_loop<STATS>(mem, sc, cam, wb, b, n_slots, cursor, stats, refill_threshold, chunk, shade_threshold);
-    } else {
-        constexpr uint32_t kTop = (uint32_t)(kTopLdsBytes / sizeof(GpuSahNode));
-        const uint32_t n_top = sc.n_xnodes < kTop ? sc.n_xnodes : kTop;
-        stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
-        TopLdsMem<GpuSahNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
-        paths_loop<STATS>(mem, sc, cam, wb, b, n_slots, cursor, stats, refill_threshold, chunk, shade_threshold);
     }
 }
 
@@ -952,7 +771,7 @@ hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu) {
         if (e == hipSuccess) e = prepare_traverse<true, true, true, 256>(cfg.lds_bytes, nullptr);
         return e;
     }
-    const size_t shm = (size_t)cfg.top_nodes * sizeof(GpuSahNode);
+    const size_t shm = (size_t)cfg.top_nodes * 128;
     switch (cfg.trav_block) {
         case 256: return prepare_traverse_block<256>(shm, blocks_per_cu);
         case 512: return prepare_traverse_block<512>(shm, blocks_per_cu);
@@ -971,7 +790,7 @@ template <bool SHADOW, bool STATS, bool LDS_SCENE, int BLOCK>
 static void launch_traverse_as(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                                uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
                                hipStream_t st) {
-    const size_t shm = LDS_SCENE ? cfg.lds_bytes : (size_t)cfg.top_nodes * sizeof(GpuSahNode);
+    const size_t shm = LDS_SCENE ? cfg.lds_bytes : (size_t)cfg.top_nodes * 128;
     hipLaunchKernelGGL((k_traverse<SHADOW, STATS, LDS_SCENE, BLOCK>), dim3(cfg.persistent_blocks), dim3(BLOCK), shm, st, sc, wb,
                        queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.top_nodes, cfg.leaf_threshold);
 }
@@ -1003,41 +822,6 @@ hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* qu
 hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t* cursor,
                       const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
     return launch_traverse<true>(sc, wb, nullptr, shadow_count, 0, cursor, cfg, stats, st);
-}
-
-template <int WAVES>
-static hipError_t launch_paths(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t n_slots,
-                               uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    dim3 grid(cfg.paths_blocks), block(kBlock);
-    const size_t shm = cfg.lds_scene ? cfg.lds_bytes : kTopLdsBytes;
-    if (stats) {
-        if (cfg.lds_scene) hipLaunchKernelGGL((k_paths<true, true, WAVES>), grid, block, shm, st, sc, cam, wb, b, n_slots, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.shade_threshold);
-        else hipLaunchKernelGGL((k_paths<true, false, WAVES>), grid, block, shm, st, sc, cam, wb, b, n_slots, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.shade_threshold);
-    } else {
-        if (cfg.lds_scene) hipLaunchKernelGGL((k_paths<false, true, WAVES>), grid, block, shm, st, sc, cam, wb, b, n_slots, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.shade_threshold);
-        else hipLaunchKernelGGL((k_paths<false, false, WAVES>), grid, block, shm, st, sc, cam, wb, b, n_slots, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.shade_threshold);
-    }
-    return hipGetLastError();
-}
-
-hipError_t wf_paths(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t n_slots,
-                    uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    switch (cfg.paths_waves) {
-        case 2: return launch_paths<2>(sc, cam, wb, b, n_slots, cursor, cfg, stats, st);
-        case 3: return launch_paths<3>(sc, cam, wb, b, n_slots, cursor, cfg, stats, st);
-        default: return launch_paths<4>(sc, cam, wb, b, n_slots, cursor, cfg, stats, st);
-    }
-}
-
-hipError_t wf_paths_blocks_per_cu(bool lds_scene, size_t lds_bytes, int waves, int* out) {
-    int n = 0;
-    hipError_t e;
-    const size_t shm = lds_scene ? lds_bytes : kTopLdsBytes;
-    if (waves == 2) e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<false, true, 2>, kBlock, shm) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<false, false, 2>, kBlock, shm);
-    else if (waves == 3) e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<false, true, 3>, kBlock, shm) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<false, false, 3>, kBlock, shm);
-    else e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<false, true, 4>, kBlock, shm) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<false, false, 4>, kBlock, shm);
-    *out = n < 1 ? 1 : n;
-    return e;
 }
 
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
