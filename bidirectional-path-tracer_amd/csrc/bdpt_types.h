@@ -58,8 +58,7 @@ static_assert(sizeof(GpuWideNode) == 128, "GpuWideNode must stay 128 bytes");
 // record; kQuadEmpty for an unused slot; otherwise a leaf, ~ref = (first << 2) | (count - 1).
 // The triangle tests stay the reference's FP64 arithmetic.
 struct GpuQuadNode {
-    float lo[4][3];
-    float hi[4][3];
+    float box[4][6];      // per child: xmin xmax ymin ymax zmin zmax (min/max of an axis adjacent: one packed FP32 operand)
     int32_t child[4];
     int32_t pad[4];
 };
@@ -109,6 +108,7 @@ struct SceneDev {
     const uint32_t* light_tris;     // the light collection (triangle ids, insertion order)
     const double* light_accum;      // running sums of the areas exactly as triangle.h:212-219 accumulates them
     double light_total_area;
+    double coord_bound;             // largest |coordinate| of any box of the closest-hit hierarchy
     uint32_t n_nodes, n_tris, n_mats, n_lights;
 };
 

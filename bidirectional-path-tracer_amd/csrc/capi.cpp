@@ -538,6 +538,7 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     d.light_tris = reinterpret_cast<const uint32_t*>(base + off_ltri);
     d.light_accum = reinterpret_cast<const double*>(base + off_lacc);
     d.light_total_area = h.light_total_area;
+    d.coord_bound = h.coord_bound;
     d.n_nodes = (uint32_t)h.nodes.size();
     d.n_tris = (uint32_t)h.tris.size();
     d.n_mats = (uint32_t)h.mats.size();

@@ -288,8 +288,8 @@ struct QuadCollapse {
         GpuQuadNode& q = out[idx];
         for (int k = 0; k < 4; k++) {
             for (int a = 0; a < 3; a++) {
-                q.lo[k][a] = k < n ? kid[k].lo[a] : std::numeric_limits<float>::infinity();
-                q.hi[k][a] = k < n ? kid[k].hi[a] : -std::numeric_limits<float>::infinity();
+                q.box[k][2 * a] = k < n ? kid[k].lo[a] : std::numeric_limits<float>::infinity();
+                q.box[k][2 * a + 1] = k < n ? kid[k].hi[a] : -std::numeric_limits<float>::infinity();
             }
             q.child[k] = k < n ? refs[k] : kQuadEmpty;
             q.pad[k] = 0;
@@ -477,6 +477,10 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
         hoist_top_levels<4>(qc.out, kLdsTopQuadNodes, [](GpuQuadNode& q) { return &q.child[0]; });
         out.xnodes.swap(qc.out);
         out.sah_stack = qc.stack_need;
+        out.coord_bound = 0.0;
+        for (const SahRef& r : sb.refs)
+            for (int k = 0; k < 3; k++) out.coord_bound = std::fmax(out.coord_bound, std::fmax(std::fabs(r.lo[k]), std::fabs(r.hi[k])));
+        out.coord_bound = (double)round_up(out.coord_bound * 1.0000002);     // covers the outward FP32 rounding of the boxes
         out.xtris.resize(sb.leaf_order.size());
         for (size_t k = 0; k < sb.leaf_order.size(); k++) {
             GpuTri t = out.stris[sb.leaf_order[k]];

@@ -19,6 +19,7 @@ struct HostScene {
     std::vector<GpuTri> stris;           // triangles in leaf order (pad = original id)
     std::vector<GpuQuadNode> xnodes;     // closest-hit hierarchy (binned SAH, four children per record)
     std::vector<GpuTri> xtris;           // its triangles in leaf order (pad = position in stris)
+    double coord_bound = 0.0;            // largest |coordinate| of its boxes
     uint32_t sah_stack = 0;              // most entries its traversal stack can hold at once
     std::vector<GpuTriAux> aux;
     std::vector<GpuMaterial> mats;

@@ -161,15 +161,49 @@ struct TopLdsMem {
     BDPT_DEV GpuTri stri(uint32_t i) const { return st[i]; }
 };
 
-// FP32 boxes (closest-hit hierarchy) only have to be conservative, not the reference's own tests: the
-// same intervals with min/max instructions instead of compare + select pairs.
-BDPT_DEV void slab(const float* blo, const float* bhi, V3 o, double ix, double iy, double iz, double closest, double& lo,
-                   double& hi) {
-    const double x0 = ((double)blo[0] - o.x) * ix, x1 = ((double)bhi[0] - o.x) * ix;
-    const double y0 = ((double)blo[1] - o.y) * iy, y1 = ((double)bhi[1] - o.y) * iy;
-    const double z0 = ((double)blo[2] - o.z) * iz, z1 = ((double)bhi[2] - o.z) * iz;
-    lo = __builtin_fmax(__builtin_fmax(__builtin_fmin(x0, x1), __builtin_fmin(y0, y1)), __builtin_fmax(__builtin_fmin(z0, z1), 0.001));
-    hi = __builtin_fmin(__builtin_fmin(__builtin_fmax(x0, x1), __builtin_fmax(y0, y1)), __builtin_fmin(__builtin_fmax(z0, z1), closest));
+// Box tests of the closest-hit hierarchy only have to be conservative, so they run in packed FP32 with
+// the rounding error carried explicitly.  Per axis the ray keeps inv = fl(1/d) and the pair
+// (c_min, c_max) = fl(-o/d) -/+ slack; the distances to the two planes of a box are then ONE packed fma,
+// (box_min, box_max) * inv + (c_min, c_max) for 1/d > 0 (pair swapped otherwise), giving a lower bound of
+// the distance to the near plane and an upper bound of the distance to the far plane:
+//   | fl(b*inv + c) - (b - o)/d |  <=  (|b| + |o| + |b - o|) * 2^-24 / |d| * (1 + tiny)  <=  slack
+// with slack = (bound + |o|) * 2^-21 / |d| (bound = largest |coordinate| of any box), four times the bound.
+// A NaN (0 * inf, inf - inf: rays parallel to an axis) is dropped by min/max, i.e. that plane does not
+// constrain the interval - never a wrong cull.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct RayF32 {
+    f2 inv[3];      // (1/d, 1/d)
+    f2 c[3];        // additive terms of the (min, max) planes
+};
+BDPT_DEV RayF32 ray_f32(V3 o, double ix, double iy, double iz, double bound) {
+    RayF32 r;
+    const double oo[3] = {o.x, o.y, o.z}, ii[3] = {ix, iy, iz};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float inv = (float)ii[a];
+        const float c = (float)(-(oo[a] * ii[a]));
+        const float slack = (float)((bound + __builtin_fabs(oo[a])) * 0x1p-21 * __builtin_fabs(ii[a])) * 1.0000002f;
+        r.inv[a] = (f2){inv, inv};
+        // 1/d > 0: the min plane is the near one (gets -slack); 1/d < 0: the max plane is
+        r.c[a] = (ii[a] >= 0.0) ? (f2){c - slack, c + slack} : (f2){c + slack, c - slack};
+    }
+    return r;
+}
+// near / far distance bounds of one child box; the ray enters it iff !(far < near)
+BDPT_DEV void slab_f32(const float* box, const RayF32& r, float closest_up, float& near, float& far) {
+    const f2 tx = __builtin_elementwise_fma((f2){box[0], box[1]}, r.inv[0], r.c[0]);
+    const f2 ty = __builtin_elementwise_fma((f2){box[2], box[3]}, r.inv[1], r.c[1]);
+    const f2 tz = __builtin_elementwise_fma((f2){box[4], box[5]}, r.inv[2], r.c[2]);
+    near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)),
+                           __builtin_fmaxf(__builtin_fminf(tz.x, tz.y), 0x1.0624dcp-10f));      // largest FP32 number below 0.001
+    far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)),
+                          __builtin_fminf(__builtin_fmaxf(tz.x, tz.y), closest_up));
+}
+// smallest FP32 number >= x (x > 0 or +infinity)
+BDPT_DEV float float_up(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + 1u);
+    return f;
 }
 
 template <class T>
@@ -194,15 +228,11 @@ BDPT_DEV void slab(const T* blo, const T* bhi, V3 o, double ix, double iy, doubl
 }
 
 // A child the ray enters, as one 64-bit word that orders like its entry distance: high half = the bits
-// of the distance as a positive FP32 number rounded DOWN (so culling against it later stays
-// conservative), low half = the child reference.  Read as an FP64 number the word is positive and
-// finite, and larger distance <=> larger number, so a compare-exchange is one min and one max
-// instruction.  Children the ray misses get +infinity and sort last.
-BDPT_DEV double quad_entry(bool in, double lo, int32_t child) {
-    float f = (float)lo;                                   // lo >= 0.001 > 0
-    uint32_t bits = __float_as_uint(f);
-    if ((double)f > lo) bits -= 1u;                        // next FP32 number towards zero
-    if (!in) bits = 0x7F800000u;
+// of the (positive FP32) lower bound of the distance, low half = the child reference.  Read as an FP64
+// number the word is positive and finite, and larger distance <=> larger number, so a compare-exchange
+// is one min and one max instruction.  Children the ray misses get +infinity and sort last.
+BDPT_DEV double quad_entry(bool in, float near, int32_t child) {
+    const uint32_t bits = in ? __float_as_uint(near) : 0x7F800000u;
     return __longlong_as_double((long long)(((unsigned long long)bits << 32) | (uint32_t)child));
 }
 BDPT_DEV int32_t quad_entry_child(double e) { return (int32_t)(uint32_t)(unsigned long long)__double_as_longlong(e); }
@@ -221,7 +251,7 @@ BDPT_DEV void sort2(double& a, double& b) {
 template <bool SHADOW, bool STATS, class Mem>
 BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffers& wb, const uint32_t* queue, uint32_t count,
                              uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk,
-                             const int kLeafThreshold) {
+                             const int kLeafThreshold, const double coord_bound) {
     bool has = false;
     uint32_t slot = 0;
     int32_t cur = kPop;                 // interior record to visit next (when leaf_left == 0)
@@ -234,6 +264,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
     unsigned long long tag = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     double ix = 0, iy = 0, iz = 0, closest = 0;
+    RayF32 rf = {};                     // closest hit only
     HitLite h;
     h.t = 0; h.u = 0; h.v = 0; h.tri = -1;
     int32_t best_pos = -1;
@@ -274,6 +305,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
                     }
                     if (!SHADOW || tmax0 >= 0.0) {              // a negative max_t marks an unused queue entry
                         ix = 1.0 / d.x; iy = 1.0 / d.y; iz = 1.0 / d.z;       // aabb.h:48, once per ray
+                        if (!SHADOW) rf = ray_f32(o, ix, iy, iz, coord_bound);
                         closest = tmax0;
                         cur = 0;
                         leaf_left = 0;
@@ -318,12 +350,13 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
                     // four children: sort the ones the ray enters by entry distance, go to the nearest, push the rest
                     double e[4];
                     int n_in = 0;
+                    const float closest_up = float_up(closest);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        double lo, hi;
-                        slab(nd.lo[k], nd.hi[k], o, ix, iy, iz, closest, lo, hi);
-                        const bool in = (nd.child[k] != kQuadEmpty) && !(hi <= lo);
-                        e[k] = quad_entry(in, lo, nd.child[k]);
+                        float near, far;
+                        slab_f32(nd.box[k], rf, closest_up, near, far);
+                        const bool in = (nd.child[k] != kQuadEmpty) && !(far < near);
+                        e[k] = quad_entry(in, near, nd.child[k]);
                         n_in += in ? 1 : 0;
                     }
                     if (STATS) n_box_hits += (uint32_t)n_in;
@@ -366,7 +399,8 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
                     if (!(closest <= e_lo)) { cur = e_node; done = false; break; }    // aabb.h:61 with the current bound
                 } else {
                     const double e = stk_quad[sp];
-                    if (!(closest <= (double)quad_entry_near(e))) { cur = quad_entry_child(e); done = false; break; }
+                    // strict: a triangle at exactly the running distance may still win the tie
+                    if (!(closest < (double)quad_entry_near(e))) { cur = quad_entry_child(e); done = false; break; }
                 }
             }
         }
@@ -438,13 +472,13 @@ __global__ __launch_bounds__(BLOCK) void k_traverse(SceneDev sc, WfBuffers wb, c
             GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_wnodes);
             stage_tree(sc.wnodes, sc.n_wnodes, sc.stris, sc.n_tris, l_nodes, l_tris);
             TreeMem<GpuWideNode> mem{l_nodes, l_tris};
-            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold);
+            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound);
         } else {
             GpuWideNode* l_nodes = reinterpret_cast<GpuWideNode*>(smem);
             const uint32_t n_top = sc.n_wnodes < top_nodes ? sc.n_wnodes : top_nodes;
             stage_tree(sc.wnodes, n_top, sc.stris, 0u, l_nodes, (GpuTri*)nullptr);
             TopLdsMem<GpuWideNode> mem{l_nodes, sc.wnodes, sc.stris, (int32_t)n_top};
-            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold);
+            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound);
         }
     } else {
         if (LDS_SCENE) {
@@ -452,13 +486,13 @@ __global__ __launch_bounds__(BLOCK) void k_traverse(SceneDev sc, WfBuffers wb, c
             GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
             stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
             TreeMem<GpuQuadNode> mem{l_nodes, l_tris};
-            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold);
+            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound);
         } else {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
             stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
             TopLdsMem<GpuQuadNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
-            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold);
+            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound);
         }
     }
 }
