@@ -66,6 +66,13 @@ class SceneInfo(C.Structure):
                 ("device_bytes", C.c_uint64)]
 
 
+class SceneFileView(C.Structure):
+    _fields_ = [("camera", CameraPublic), ("output_name", C.c_char_p), ("tri_vertices", C.POINTER(C.c_double)),
+                ("tri_material", C.POINTER(C.c_int32)), ("materials", C.POINTER(Material)),
+                ("light_triangles", C.POINTER(C.c_uint32)), ("n_triangles", C.c_uint32), ("n_materials", C.c_uint32),
+                ("n_lights", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 # every symbol include/bdpt_amd.h declares
 EXPORTED_SYMBOLS = [
     "bdpt_last_error", "bdpt_context_create", "bdpt_context_destroy", "bdpt_camera_initialize", "bdpt_scene_create",
@@ -73,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "bdpt_trace_closest_device", "bdpt_visible", "bdpt_render", "bdpt_render_device", "bdpt_render_get_stats",
     "bdpt_render_get_kernel_ms", "bdpt_render_get_stage_ms",
     "bdpt_colors_to_rgb8", "bdpt_colors_to_rgb8_device", "bdpt_device_sincos", "bdpt_device_random_doubles",
-    "bdpt_device_arith",
+    "bdpt_device_arith", "bdpt_scene_file_load", "bdpt_scene_file_destroy", "bdpt_scene_file_get", "bdpt_write_png", "bdpt_debug_yaml_to_json",
 ]
 
 _lib = None
@@ -118,6 +125,11 @@ def load_library() -> C.CDLL:
     lib.bdpt_device_sincos.argtypes = [vp, vp, u64, vp, vp]
     lib.bdpt_device_random_doubles.argtypes = [vp, u64, u64, u64, u64, vp]
     lib.bdpt_device_arith.argtypes = [vp, C.c_int, vp, vp, u64, vp]
+    lib.bdpt_scene_file_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.bdpt_scene_file_destroy.argtypes = [vp]
+    lib.bdpt_scene_file_get.argtypes = [vp, C.POINTER(SceneFileView)]
+    lib.bdpt_write_png.argtypes = [C.c_char_p, vp, C.c_int32, C.c_int32]
+    lib.bdpt_debug_yaml_to_json.argtypes = [C.c_char_p, C.c_char_p, u64]
     for name in EXPORTED_SYMBOLS:
         if name != "bdpt_last_error":
             getattr(lib, name).restype = C.c_int
@@ -151,6 +163,48 @@ def camera_initialize(cam) -> CameraState:
     pub = cam if isinstance(cam, CameraPublic) else camera_public_from(cam)
     _check(load_library().bdpt_camera_initialize(C.byref(pub), C.byref(st)))
     return st
+
+
+def load_scene_file(path: str):
+    """load_scene_from_yaml through the library: returns a scenes.FlatScene (camera.file_name = output name)."""
+    from . import scenes
+    lib = load_library()
+    h = C.c_void_p()
+    _check(lib.bdpt_scene_file_load(os.fsencode(path), C.byref(h)))
+    try:
+        v = SceneFileView()
+        _check(lib.bdpt_scene_file_get(h, C.byref(v)))
+        flat = scenes.FlatScene()
+        c = v.camera
+        flat.camera = scenes.Camera(aspect_ratio=c.aspect_ratio, image_width=c.image_width, samples_per_pixel=c.samples_per_pixel,
+                                    max_depth=c.max_depth, background=tuple(c.background), vfov=c.vfov, lookfrom=tuple(c.lookfrom),
+                                    lookat=tuple(c.lookat), vup=tuple(c.vup), defocus_angle=c.defocus_angle,
+                                    focus_dist=c.focus_dist, file_name=v.output_name.decode())
+        for i in range(v.n_materials):
+            m = v.materials[i]
+            flat.materials.append(scenes.Material(int(m.type), tuple(m.rgb), float(m.fuzz), float(m.ior)))
+        n = int(v.n_triangles)
+        if n:
+            flat.vertices = np.ctypeslib.as_array(v.tri_vertices, shape=(n, 9)).copy().tolist()
+            flat.tri_material = np.ctypeslib.as_array(v.tri_material, shape=(n,)).copy().tolist()
+        flat.lights = [int(v.light_triangles[i]) for i in range(v.n_lights)]
+        return flat
+    finally:
+        lib.bdpt_scene_file_destroy(h)
+
+
+def yaml_to_json(text: str):
+    """Parse tree of the library's YAML reader (test hook): dicts, lists, strings, None."""
+    import json
+    buf = C.create_string_buffer(max(4096, 8 * len(text) + 64))
+    _check(load_library().bdpt_debug_yaml_to_json(text.encode("utf-8"), buf, len(buf)))
+    return json.loads(buf.value.decode("utf-8"))
+
+
+def write_png(file_name: str, rgb: np.ndarray) -> None:
+    """8-bit RGB PNG at ./output/<file_name> (src/image/wpng.h:38-89)."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    _check(load_library().bdpt_write_png(os.fsencode(file_name), _ptr(rgb), rgb.shape[1], rgb.shape[0]))
 
 
 def colors_to_rgb8(fb: np.ndarray, spp: int) -> np.ndarray:

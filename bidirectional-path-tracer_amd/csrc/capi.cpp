@@ -410,6 +410,8 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
 extern "C" {
 
 const char* bdpt_last_error(void) { return g_last_error.c_str(); }
+// used by the host-side sources of this library (scene files), not part of the public header
+void bdpt_internal_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 
 int bdpt_context_create(int device_index, bdpt_context** out) {
     if (!out) return fail(BDPT_ERR_INVALID_ARGUMENT, "null output pointer");

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 namespace bdpt {
@@ -114,6 +115,8 @@ struct SahBuilder {
     std::vector<SahBinNode> nodes;
     std::vector<uint32_t> leaf_order;      // positions (in stris) in this hierarchy's leaf order
     uint32_t max_depth = 0;
+    size_t min_leaf = 2;       // ranges of at most this many triangles always become a leaf
+    double box_cost = 1.0;     // cost of one record visit in units of one triangle test
 
     static double area(const double* lo, const double* hi) {
         const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -133,7 +136,7 @@ struct SahBuilder {
     int32_t build(size_t a, size_t b, uint32_t depth) {
         if (depth > max_depth) max_depth = depth;
         const size_t n = b - a;
-        if (n <= 2) return make_leaf(a, b);
+        if (n <= min_leaf) return make_leaf(a, b);
         double clo[3], chi[3];
         for (int k = 0; k < 3; k++) { clo[k] = std::numeric_limits<double>::infinity(); chi[k] = -clo[k]; }
         for (size_t i = a; i < b; i++)
@@ -186,7 +189,7 @@ struct SahBuilder {
             bounds(a, b, lo, hi);
             const double parent = area(lo, hi);
             // leaf cost n * 1.0 against split cost 1.0 + children (box test taken as one triangle test)
-            if (n <= 4 && parent > 0 && best_cost / parent + 1.0 >= (double)n) return make_leaf(a, b);
+            if (n <= 4 && parent > 0 && best_cost / parent + box_cost >= (double)n) return make_leaf(a, b);
             const double ext = chi[best_axis] - clo[best_axis];
             const double scale = kBins / ext;
             const double c0 = clo[best_axis];
@@ -443,6 +446,8 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
     // closest-hit hierarchy over the same triangles (referenced by their position in `stris`)
     {
         SahBuilder sb;
+        if (const char* v = std::getenv("BDPT_SAH_MIN_LEAF")) sb.min_leaf = (size_t)std::atoi(v);
+        if (const char* v = std::getenv("BDPT_SAH_BOX_COST")) sb.box_cost = std::atof(v);
         sb.refs.resize(out.stris.size());
         for (size_t p = 0; p < out.stris.size(); p++) {
             const uint32_t id = (uint32_t)out.stris[p].pad;

@@ -104,6 +104,9 @@ typedef struct bdpt_render_params {
                                        wavefront pipeline; same framebuffer bit for bit (BDPT_RENDER_COUNT_STATS implies it) */
 #define BDPT_RENDER_TIME_KERNEL 4   /* bracket the render kernels of the call with HIP events on the caller's stream
                                        (bdpt_render_get_kernel_ms) */
+#define BDPT_RENDER_UNIDIRECTIONAL 32 /* estimate with camera::path_trace_color (src/camera.h:255-292: mixture of light and
+                                       BSDF sampling) instead of bidirectional_color - what the reference's ray_color
+                                       does when `lights` is not a triangle_collection (camera.h:245-253) */
 #define BDPT_RENDER_TIME_STAGES 16  /* additionally record a HIP event pair around every ray-traversal launch, on the
                                        internal stream it is launched on (bdpt_render_get_stage_ms); wavefront pipeline only */
 
@@ -204,6 +207,34 @@ int bdpt_colors_to_rgb8(const double* framebuffer, int32_t width, int32_t height
                         uint8_t* out_rgb);
 int bdpt_colors_to_rgb8_device(bdpt_context* ctx, const void* d_framebuffer, int32_t width, int32_t height,
                                int32_t samples_per_pixel, void* d_out_rgb, void* stream);
+
+/* ---- scene files and image output (host only, no GPU work) ---- */
+/* load_scene_from_yaml(path), src/scene/scene_loader.h:480-523, without yaml-cpp: the camera block (:427-476),
+ * the named materials (:173-188, build_material :101-170), and the surfaces `TriMesh` (:244-272), `Sphere`
+ * (16 x 32 tessellation, :212-242,274-294), `mesh` (:297-343) and `object` = Wavefront OBJ file with `v` / `f`
+ * lines, negative indices and fan triangulation (:346-425).  The result is the flat input of bdpt_scene_create:
+ * triangles in the order triangle_collection::add received them, materials in order of creation, and the ids of
+ * the triangles the loader also put into `lights` (:190-202).  Errors (what the reference throws) return
+ * BDPT_ERR_INVALID_ARGUMENT with the reference's message in bdpt_last_error(). */
+typedef struct bdpt_scene_file bdpt_scene_file;
+typedef struct bdpt_scene_file_view {
+    bdpt_camera_public camera;
+    const char* output_name;            /* camera::file_name, "image.png" unless the file names one */
+    const double* tri_vertices;         /* n_triangles * 9 */
+    const int32_t* tri_material;
+    const bdpt_material* materials;
+    const uint32_t* light_triangles;
+    uint32_t n_triangles, n_materials, n_lights, reserved;
+} bdpt_scene_file_view;
+int bdpt_scene_file_load(const char* yaml_path, bdpt_scene_file** out);
+int bdpt_scene_file_destroy(bdpt_scene_file* file);
+/* Pointers stay valid until bdpt_scene_file_destroy. */
+int bdpt_scene_file_get(const bdpt_scene_file* file, bdpt_scene_file_view* out);
+/* write_png(filename, rgb, W, H), src/image/wpng.h:38-89: 8-bit RGB PNG at ./output/<file_name> (directory created). */
+int bdpt_write_png(const char* file_name, const uint8_t* rgb, int32_t width, int32_t height);
+
+/* Test hook: the parse tree of a YAML text (the subset the scene files use) as JSON, scalars as strings. */
+int bdpt_debug_yaml_to_json(const char* text, char* out, uint64_t capacity);
 
 /* Test hooks for the device-side building blocks the path is made of. */
 /* std::cos / std::sin of src/core/vec3.h:154-155 as evaluated on the GPU (0 <= x <= 8). */

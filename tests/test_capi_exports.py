@@ -34,6 +34,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(capi.RenderParams) == 8 + 8 * 4
     assert C.sizeof(capi.Stats) == 88
     assert C.sizeof(capi.SceneInfo) == 32
+    assert C.sizeof(capi.SceneFileView) == 144 + 5 * 8 + 4 * 4
 
 
 @pytest.mark.parametrize("builder", ["cornell", "showcase", "nolight"])

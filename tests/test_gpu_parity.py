@@ -3,6 +3,7 @@ vectors produced by the reference's own headers.  Everything here is FP64 and co
 hit records, visibility booleans, per-pixel framebuffer sums, work counters."""
 import hashlib
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 capi = importlib.import_module("bidirectional-path-tracer_amd.capi")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def bits(a):
@@ -289,3 +291,24 @@ def test_device_render_timers(scenes, ctx):
     sc.render_device(cam, fb.data_ptr(), seed=4)
     with pytest.raises(capi.BdptError):
         sc.last_stage_ms(0)
+
+
+def test_command_line_renderer_end_to_end(tmp_path, oracle):
+    """scene file -> bdpt_render (loader, GPU render, tone mapping, PNG) against the same scene rendered by the CPU
+    oracle: the decoded image must be identical byte for byte."""
+    import subprocess
+    from PIL import Image
+    exe = os.path.join(ROOT, "bidirectional-path-tracer_amd", "bdpt_render")
+    if not os.path.exists(exe):
+        pytest.skip("command-line renderer not built")
+    path = os.path.join(ROOT, "tests", "data", "scene_typed.yaml")
+    r = subprocess.run([exe, path, "--seed", "3"], capture_output=True, text=True, cwd=tmp_path, timeout=100)
+    assert r.returncode == 0, r.stderr
+    assert "Triangles: 980" in r.stdout
+    img = np.array(Image.open(tmp_path / "output" / "typed_scene.png").convert("RGB"))
+    flat = capi.load_scene_file(path)
+    cam = capi.camera_initialize(flat.camera)
+    ofb, _, _ = oracle.scene(flat).render(cam.as_array(), cam.image_width, cam.sqrt_spp, cam.max_depth, 3,
+                                          (0, 0, cam.image_width, cam.image_height))
+    want = capi.colors_to_rgb8(ofb, cam.sqrt_spp ** 2)
+    assert img.shape == want.shape and (img == want).all()
