@@ -17,6 +17,7 @@ BDPT_RENDER_COUNT_STATS = 1     # counters with the reference's BvhStats semanti
 BDPT_RENDER_COUNT_WORK = 2      # counters of the work the production path does
 BDPT_RENDER_TIME_KERNEL = 4     # HIP events around the render kernels
 BDPT_RENDER_TIME_STAGES = 16    # HIP event pair around every traversal launch
+BDPT_RENDER_UNIDIRECTIONAL = 32  # camera::path_trace_color instead of bidirectional_color
 BDPT_RENDER_MEGAKERNEL = 8      # single persistent kernel instead of the wavefront pipeline
 
 
@@ -316,11 +317,13 @@ class Scene:
         return out
 
     @staticmethod
-    def _flags(want_stats, time_kernel=False, megakernel=False, time_stages=False):
+    def _flags(want_stats, time_kernel=False, megakernel=False, time_stages=False, unidirectional=False):
         """want_stats: False / True or "reference" (BvhStats semantics) / "work" (production path's own work)"""
         f = BDPT_RENDER_TIME_KERNEL if time_kernel else 0
         if time_stages:
             f |= BDPT_RENDER_TIME_STAGES
+        if unidirectional:
+            f |= BDPT_RENDER_UNIDIRECTIONAL
         if megakernel:
             f |= BDPT_RENDER_MEGAKERNEL
         if want_stats == "work":
@@ -330,7 +333,7 @@ class Scene:
         return f
 
     def render(self, cam_state: CameraState, seed=0, rect=None, shard=(0, 1, 1), want_stats=False, framebuffer=None,
-               megakernel=False):
+               megakernel=False, unidirectional=False):
         """Host-buffer render; returns the full W x H x 3 framebuffer of sums (unowned pixels keep
         the values of `framebuffer`, zeros by default) and optionally the counters."""
         W, H = cam_state.image_width, cam_state.image_height
@@ -340,7 +343,7 @@ class Scene:
         if rect is not None:
             p.x0, p.y0, p.x1, p.y1 = [int(v) for v in rect]
         p.shard_index, p.shard_count, p.shard_rows = shard
-        p.flags = self._flags(want_stats, megakernel=megakernel)
+        p.flags = self._flags(want_stats, megakernel=megakernel, unidirectional=unidirectional)
         st = Stats()
         _check(self.lib.bdpt_render(self.ctx.h, self.h, C.byref(cam_state), C.byref(p), _ptr(fb), C.byref(st)))
         return (fb, st) if want_stats else fb

@@ -138,7 +138,7 @@ GpuCamera to_gpu_camera(const bdpt_camera_state& c) {
 
 // ---- single persistent kernel: one thread per sample does the whole of bidirectional_color
 int render_megakernel(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, uint64_t seed, int32_t n_rows,
-                      int x0, int x1, int64_t n_owned, double* d_fb, int stats_mode, hipStream_t stream) {
+                      int x0, int x1, int64_t n_owned, double* d_fb, int stats_mode, bool unidirectional, hipStream_t stream) {
     HIP_TRY(hipMemsetAsync(ctx->unit_counter, 0, sizeof(uint32_t), stream));
     const int spp = cam->sqrt_spp * cam->sqrt_spp;
     const int ppg = spp >= kBlock ? 1 : kBlock / spp;
@@ -146,7 +146,7 @@ int render_megakernel(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_cam
     if (n_units > 0x7FFFFFFF) return fail(BDPT_ERR_INVALID_ARGUMENT, "too many work units in one call");
     // persistent grid: enough workgroups to fill the chip, never more than there is work
     int per_cu = 1;
-    HIP_TRY(render_blocks_per_cu(scene->dev, stats_mode, &per_cu));
+    HIP_TRY(render_blocks_per_cu(scene->dev, stats_mode, unidirectional, &per_cu));
     int64_t grid = (int64_t)ctx->cu_count * per_cu;
     if (grid > n_units) grid = n_units;
     const size_t ws_stride = (size_t)grid * kBlock;
@@ -166,7 +166,7 @@ int render_megakernel(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_cam
     rl.vertex_ws = ctx->vertex_ws;
     rl.stats = stats_mode ? ctx->stats : nullptr;
     rl.ws_stride = ws_stride;
-    HIP_TRY(launch_render(scene->dev, to_gpu_camera(*cam), rl, (int)grid, stats_mode, stream));
+    HIP_TRY(launch_render(scene->dev, to_gpu_camera(*cam), rl, (int)grid, stats_mode, unidirectional, stream));
     return BDPT_OK;
 }
 
@@ -394,12 +394,14 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     if (want_time) HIP_TRY(hipEventRecord(ctx->ev_start, stream));
     // Reference-equivalent counters need the reference's traversal of every shadow ray: that is the
     // single-kernel path.  Everything else runs the wavefront pipeline unless the caller asks otherwise.
-    if (stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL))
-        rc = render_megakernel(ctx, scene, cam, p->seed, (int32_t)rows.size(), x0, x1, n_owned, d_fb, stats_mode, stream);
+    const bool unidirectional = (p->flags & BDPT_RENDER_UNIDIRECTIONAL) != 0;     // single-kernel path only
+    if (stats_mode == 1 || unidirectional || (p->flags & BDPT_RENDER_MEGAKERNEL))
+        rc = render_megakernel(ctx, scene, cam, p->seed, (int32_t)rows.size(), x0, x1, n_owned, d_fb, stats_mode, unidirectional,
+                               stream);
     else
         rc = render_wavefront(ctx, scene, cam, p->seed, x0, x1, n_owned, d_fb, stats_mode, time_stages, stream);
     if (rc != BDPT_OK) return rc;
-    ctx->stage_valid = time_stages && !(stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL));
+    ctx->stage_valid = time_stages && !(stats_mode == 1 || unidirectional || (p->flags & BDPT_RENDER_MEGAKERNEL));
     if (want_time) { HIP_TRY(hipEventRecord(ctx->ev_stop, stream)); ctx->timing_valid = true; }
     ctx->stats_valid = want_stats;
     return BDPT_OK;

@@ -568,5 +568,102 @@ BDPT_DEV V3 sample_radiance(const Mem& mem, const SceneDev& sc, const GpuCamera&
     return result;
 }
 
+// ------------------------------------------------------------------ unidirectional estimator
+// triangle::pdf_value, triangle.h:78-91: a hit test of this ONE triangle, not of the world
+template <int STATS>
+BDPT_DEV double light_tri_pdf(const SceneDev& sc, uint32_t tri_id, V3 origin, V3 direction, Counters& c) {
+    const GpuTri tr = sc.tris[tri_id];
+    double t, u, v;
+    if (STATS) c.tri_tests++;
+    if (!tri_test(tr, origin, direction, 0.001, kInf, t, u, v)) return 0.0;
+    if (STATS) c.tri_hits++;
+    const GpuTriAux ax = sc.aux[tri_id];
+    V3 outward = ld3(ax.normal);
+    V3 normal = (dot(direction, outward) < 0) ? outward : neg(outward);          // hittable.h:20-26
+    double distance_squared = t * t * len2(direction);
+    double cosine = __builtin_fabs(dot(direction, normal) / len(direction));
+    if (ax.area <= 0.0 || cosine <= 0.0) return 0.0;
+    return distance_squared / (cosine * ax.area);
+}
+
+// camera::path_trace_color, src/camera.h:255-292, with mixture_pdf(hittable_pdf(lights), cosine_pdf) of
+// src/acceleration/pdf.h:32-90 and triangle_collection::pdf_value / random (triangle.h:170-189).  The
+// reference recurses and combines on the way back, `emission + attenuation * scattering_pdf * sample / pdf`
+// (or `attenuation * sample` for metal and dielectric); here the walk goes forward storing one record per
+// bounce (factor and pdf) in the vertex workspace, and the same expressions are folded from the last
+// bounce to the first.
+template <int STATS, class Mem>
+BDPT_DEV V3 sample_radiance_unidirectional(const Mem& mem, const SceneDev& sc, const GpuCamera& cam, int i, int j, int s_i,
+                                           int s_j, uint64_t seed, const VertexStore& store, Counters& c, uint32_t& draws) {
+    Rng rng;
+    rng.key = stream_key(seed, (uint64_t)j * (uint64_t)cam.width + (uint64_t)i, (uint64_t)s_j * cam.sqrt_spp + s_i);
+    rng.counter = 0;
+    V3 o, d;
+    camera_ray(cam, i, j, s_i, s_j, rng, o, d);
+    int n = 0;                                  // bounces recorded (at most max_depth <= workspace slots)
+    V3 result = mk(0, 0, 0);                    // value of the innermost call
+    for (int remaining = cam.max_depth;; remaining--) {
+        if (STATS) c.rays_traced++;
+        if (remaining <= 0) break;              // camera.h:258-259
+        HitLite h;
+        if (!walk<STATS, false>(mem, o, d, 0.001, kInf, h, c)) { result = ld3(cam.background); break; }
+        const GpuTriAux ax = sc.aux[h.tri];
+        const GpuMaterial m = sc.mats[sc.tris[h.tri].material];
+        V3 p = add(o, scl(h.t, d));
+        V3 outward = ld3(ax.normal);
+        bool front_face = dot(d, outward) < 0;
+        V3 normal = front_face ? outward : neg(outward);
+        if (m.type == 3) { result = front_face ? ld3(m.rgb) : mk(0, 0, 0); break; }      // emitted, no scatter
+        Vertex rec;                              // p = factor, n.x = pdf (0 marks `attenuation * sample`)
+        rec.n = mk(0, 0, 0); rec.T = mk(0, 0, 0); rec.info = 0;
+        if (m.type == 1 || m.type == 2) {
+            Bounce bo;
+            shade_bounce<true>(sc, o, d, h, mk(1.0, 1.0, 1.0), rng, bo);      // bo.T = 1 * attenuation = attenuation
+            rec.p = bo.T;
+            store.put(n++, rec);
+            o = bo.o; d = bo.d;
+            continue;
+        }
+        // lambertian: direction from the mixture, pdf.h:73-87
+        V3 w;
+        (void)onb_transform(normal, mk(0, 0, 0), w);
+        V3 direction;
+        if (rng.next() < 0.5) {
+            // triangle_collection::random: random_int(0, size - 1) = int(0 + (size - 0) * random_double()), main.h:34-42
+            int idx = (int)(0.0 + ((double)(int)sc.n_lights - 0.0) * rng.next());
+            if (idx > (int)sc.n_lights - 1) idx = (int)sc.n_lights - 1;       // (out of range in the reference)
+            const GpuTri lt = sc.tris[sc.light_tris[idx]];
+            double u = rng.next();
+            double v = rng.next();
+            if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
+            V3 lp = add(add(ld3(lt.v0), scl(u, ld3(lt.e1))), scl(v, ld3(lt.e2)));
+            direction = sub(lp, p);
+        } else {
+            V3 w2;
+            direction = onb_transform(normal, random_cosine_direction(rng), w2);
+        }
+        // triangle_collection::pdf_value: every light triangle, in order
+        double weight = 1.0 / (double)sc.n_lights;
+        double sum = 0.0;
+        for (uint32_t k = 0; k < sc.n_lights; k++) sum += weight * light_tri_pdf<STATS>(sc, sc.light_tris[k], p, direction, c);
+        double cosine_theta = dot(unit(direction), w);
+        double pdf_value = 0.5 * sum + 0.5 * __builtin_fmax(0.0, cosine_theta / kPi);
+        if (pdf_value <= 0) break;               // returns the (zero) emission of a lambertian surface
+        double cos_theta = dot(normal, unit(direction));
+        double scattering_pdf = cos_theta < 0 ? 0 : cos_theta / kPi;
+        rec.p = scl(scattering_pdf, ld3(m.rgb));
+        rec.n.x = pdf_value;
+        store.put(n++, rec);
+        o = p; d = direction;
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        const Vertex rec = store.get(k);
+        if (rec.n.x == 0.0) result = mulv(rec.p, result);
+        else result = add(mk(0, 0, 0), divs(mulv(rec.p, result), rec.n.x));
+    }
+    draws = rng.counter;
+    return result;
+}
+
 }  // namespace bdpt
 #endif

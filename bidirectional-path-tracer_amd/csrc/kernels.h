@@ -15,10 +15,11 @@ constexpr size_t kSceneLdsLimit = 64 * 1024;
 
 bool scene_fits_lds(const SceneDev& sc);
 
-hipError_t render_blocks_per_cu(const SceneDev& sc, int stats_mode, int* out);
+hipError_t render_blocks_per_cu(const SceneDev& sc, int stats_mode, bool unidirectional, int* out);
 // stats_mode: 0 none, 1 reference-equivalent counters, 2 counters of the work really done
+// unidirectional: camera::path_trace_color instead of bidirectional_color (counters then always have the reference's meaning)
 hipError_t launch_render(const SceneDev& sc, const GpuCamera& cam, const RenderLaunch& rl, int grid_blocks, int stats_mode,
-                         hipStream_t stream);
+                         bool unidirectional, hipStream_t stream);
 hipError_t launch_trace_closest(const SceneDev& sc, const double* d_rays, uint64_t n, double* d_hits,
                                 unsigned long long* d_stats, hipStream_t stream);
 hipError_t launch_visible(const SceneDev& sc, const double* d_pairs, uint64_t n, uint8_t* d_out, hipStream_t stream);

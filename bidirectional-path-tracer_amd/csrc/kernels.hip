@@ -39,7 +39,7 @@ __device__ __forceinline__ void flush_counters(const Counters& c, uint32_t draws
 // renders one sample; the per-pixel SUM is formed in the reference's order (s_j outer, s_i inner,
 // camera.h:118-123) by one lane per colour channel reading the samples from LDS, so the FP64 sum
 // is bit-identical to the sequential loop.
-template <int STATS, bool LDS_SCENE>
+template <int STATS, bool LDS_SCENE, bool UNIDIRECTIONAL = false>
 __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev sc, GpuCamera cam, RenderLaunch rl) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* l_samples = reinterpret_cast<double*>(smem);                 // kBlock * 3
@@ -86,10 +86,12 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev sc, GpuCamera c
                 uint32_t draws = 0;
                 if (LDS_SCENE) {
                     LdsScene mem{l_nodes, l_tris};
-                    col = sample_radiance<STATS>(mem, sc, cam, i, j, s_i, s_j, rl.seed, store, c, draws);
+                    col = UNIDIRECTIONAL ? sample_radiance_unidirectional<STATS>(mem, sc, cam, i, j, s_i, s_j, rl.seed, store, c, draws)
+                                         : sample_radiance<STATS>(mem, sc, cam, i, j, s_i, s_j, rl.seed, store, c, draws);
                 } else {
                     GlobalScene mem{sc.nodes, sc.tris};
-                    col = sample_radiance<STATS>(mem, sc, cam, i, j, s_i, s_j, rl.seed, store, c, draws);
+                    col = UNIDIRECTIONAL ? sample_radiance_unidirectional<STATS>(mem, sc, cam, i, j, s_i, s_j, rl.seed, store, c, draws)
+                                         : sample_radiance<STATS>(mem, sc, cam, i, j, s_i, s_j, rl.seed, store, c, draws);
                 }
                 total_draws += draws;
                 total_samples++;
@@ -219,11 +221,22 @@ static hipError_t occupancy_of(size_t shmem, int* n) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, render_kernel<STATS, LDS>, kBlock, shmem);
 }
 
-hipError_t render_blocks_per_cu(const SceneDev& sc, int stats_mode, int* out) {
+template <int STATS, bool LDS>
+static hipError_t occupancy_of_unidirectional(size_t shmem, int* n) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, render_kernel<STATS, LDS, true>, kBlock, shmem);
+}
+
+hipError_t render_blocks_per_cu(const SceneDev& sc, int stats_mode, bool unidirectional, int* out) {
     const bool lds = scene_fits_lds(sc);
     const size_t shmem = sizeof(double) * kBlock * 6 + (lds ? scene_lds_bytes(sc) : 0);
     int n = 0;
     hipError_t e;
+    if (unidirectional) {
+        if (stats_mode != kStatsOff) e = lds ? occupancy_of_unidirectional<kStatsReference, true>(shmem, &n) : occupancy_of_unidirectional<kStatsReference, false>(shmem, &n);
+        else e = lds ? occupancy_of_unidirectional<kStatsOff, true>(shmem, &n) : occupancy_of_unidirectional<kStatsOff, false>(shmem, &n);
+        *out = n < 1 ? 1 : n;
+        return e;
+    }
     if (stats_mode == kStatsReference) e = lds ? occupancy_of<kStatsReference, true>(shmem, &n) : occupancy_of<kStatsReference, false>(shmem, &n);
     else if (stats_mode == kStatsWork) e = lds ? occupancy_of<kStatsWork, true>(shmem, &n) : occupancy_of<kStatsWork, false>(shmem, &n);
     else e = lds ? occupancy_of<kStatsOff, true>(shmem, &n) : occupancy_of<kStatsOff, false>(shmem, &n);
@@ -232,10 +245,20 @@ hipError_t render_blocks_per_cu(const SceneDev& sc, int stats_mode, int* out) {
 }
 
 hipError_t launch_render(const SceneDev& sc, const GpuCamera& cam, const RenderLaunch& rl, int grid_blocks, int stats_mode,
-                         hipStream_t stream) {
+                         bool unidirectional, hipStream_t stream) {
     const bool lds = scene_fits_lds(sc);
     size_t shmem = sizeof(double) * kBlock * 6 + (lds ? scene_lds_bytes(sc) : 0);
     dim3 grid(grid_blocks), block(kBlock);
+    if (unidirectional) {
+        if (stats_mode != kStatsOff) {
+            if (lds) hipLaunchKernelGGL((render_kernel<kStatsReference, true, true>), grid, block, shmem, stream, sc, cam, rl);
+            else hipLaunchKernelGGL((render_kernel<kStatsReference, false, true>), grid, block, shmem, stream, sc, cam, rl);
+        } else {
+            if (lds) hipLaunchKernelGGL((render_kernel<kStatsOff, true, true>), grid, block, shmem, stream, sc, cam, rl);
+            else hipLaunchKernelGGL((render_kernel<kStatsOff, false, true>), grid, block, shmem, stream, sc, cam, rl);
+        }
+        return hipGetLastError();
+    }
     if (stats_mode == kStatsReference) {
         if (lds) hipLaunchKernelGGL((render_kernel<kStatsReference, true>), grid, block, shmem, stream, sc, cam, rl);
         else hipLaunchKernelGGL((render_kernel<kStatsReference, false>), grid, block, shmem, stream, sc, cam, rl);

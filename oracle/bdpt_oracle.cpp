@@ -523,6 +523,89 @@ V3 bidirectional_color(const oracle_scene& s, const Camera& cam, const std::vect
     return result;
 }
 
+// triangle::pdf_value, triangle.h:78-91: a hit test of this one triangle (not of the world)
+double tri_pdf_value(const oracle_scene& s, uint32_t id, V3 origin, V3 direction, Stats& st) {
+    Hit rec;
+    Ray r;
+    r.o = origin; r.d = direction;
+    if (!tri_hit(s, (int32_t)id, r, 0.001, kInfinity, rec, st)) return 0.0;
+    const Tri& tr = s.tris[id];
+    double distance_squared = rec.t * rec.t * len2(direction);
+    double cosine = std::fabs(dot(direction, rec.normal) / len(direction));
+    if (tr.area <= 0.0 || cosine <= 0.0) return 0.0;
+    return distance_squared / (cosine * tr.area);
+}
+
+// triangle_collection::pdf_value, triangle.h:170-181
+double lights_pdf_value(const oracle_scene& s, const std::vector<uint32_t>& lights, V3 origin, V3 direction, Stats& st) {
+    if (lights.empty()) return 0.0;
+    double weight = 1.0 / lights.size();
+    double sum = 0.0;
+    for (uint32_t id : lights) sum += weight * tri_pdf_value(s, id, origin, direction, st);
+    return sum;
+}
+
+// triangle_collection::random + triangle::random, triangle.h:183-189,93-103; random_int, main.h:39-42
+V3 lights_random(const oracle_scene& s, const std::vector<uint32_t>& lights, V3 origin, Rng& rng) {
+    if (lights.empty()) return mk(1, 0, 0);
+    int idx = int(rng.next(0, static_cast<int>(lights.size()) - 1 + 1));
+    const Tri& tr = s.tris[lights[idx]];
+    double u = rng.next();
+    double v = rng.next();
+    if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
+    V3 p = add(add(tr.v0, scl(u, tr.edge1)), scl(v, tr.edge2));
+    return sub(p, origin);
+}
+
+// camera::path_trace_color, camera.h:255-292 (mixture_pdf / hittable_pdf / cosine_pdf: pdf.h:32-90)
+V3 path_trace_color(const oracle_scene& s, const Camera& cam, const std::vector<uint32_t>& lights, const Ray& r, int depth,
+                    Rng& rng, Stats& st) {
+    st.rays_traced++;
+    if (depth <= 0) return mk(0, 0, 0);
+    Hit rec;
+    if (!world_hit(s, r, 0.001, kInfinity, rec, st)) return cam.background;
+    const Mat& m = s.mats[rec.mat];
+    V3 color_from_emission = mat_emitted(m, rec.front_face);
+    if (m.type == ORACLE_DIFFUSE_LIGHT) return color_from_emission;              // scatter() == false
+    if (m.type == ORACLE_METAL) {                                                // material.h:73-83
+        V3 reflected = reflect(r.d, rec.normal);
+        reflected = add(unit(reflected), scl(m.fuzz, random_unit_vector(rng)));
+        Ray next;
+        next.o = rec.p; next.d = reflected;
+        return mulv(m.rgb, path_trace_color(s, cam, lights, next, depth - 1, rng, st));
+    }
+    if (m.type == ORACLE_DIELECTRIC) {                                           // material.h:96-116
+        double ri = rec.front_face ? (1.0 / m.ior) : m.ior;
+        V3 unit_direction = unit(r.d);
+        double cos_theta = std::fmin(dot(neg(unit_direction), rec.normal), 1.0);
+        double sin_theta = std::sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = ri * sin_theta > 1.0;
+        V3 direction;
+        if (cannot_refract || reflectance(cos_theta, ri) > rng.next())
+            direction = reflect(unit_direction, rec.normal);
+        else
+            direction = refract(unit_direction, rec.normal, ri);
+        Ray next;
+        next.o = rec.p; next.d = direction;
+        return mulv(mk(1.0, 1.0, 1.0), path_trace_color(s, cam, lights, next, depth - 1, rng, st));
+    }
+    // lambertian: mixture of the light pdf and the cosine pdf
+    Onb uvw = make_onb(rec.normal);
+    V3 direction;
+    if (rng.next() < 0.5) direction = lights_random(s, lights, rec.p, rng);
+    else direction = onb_transform(uvw, random_cosine_direction(rng));
+    double cosine_theta = dot(unit(direction), uvw.a2);
+    double pdf_value = 0.5 * lights_pdf_value(s, lights, rec.p, direction, st) + 0.5 * std::fmax(0, cosine_theta / kPi);
+    if (pdf_value <= 0) return color_from_emission;
+    double cos_theta = dot(rec.normal, unit(direction));
+    double scattering_pdf = cos_theta < 0 ? 0 : cos_theta / kPi;
+    Ray scattered;
+    scattered.o = rec.p; scattered.d = direction;
+    V3 sample_color = path_trace_color(s, cam, lights, scattered, depth - 1, rng, st);
+    V3 color_from_scatter = divs(mulv(scl(scattering_pdf, m.rgb), sample_color), pdf_value);
+    return add(color_from_emission, color_from_scatter);
+}
+
 // camera.h:199-223 (defocus_angle <= 0: the loader forces it to 0, src/scene/scene_loader.h:463)
 Ray get_ray(const Camera& cam, int i, int j, int s_i, int s_j, double recip_sqrt_spp, Rng& rng) {
     double px = ((s_i + rng.next()) * recip_sqrt_spp) - 0.5;
@@ -708,9 +791,9 @@ void oracle_visible(const oracle_scene* s, const double* pairs, uint64_t n, doub
     }
 }
 
-void oracle_render(const oracle_scene* s, const double* camera, int32_t W, int32_t sqrt_spp, int32_t max_depth,
-                   uint64_t seed, int32_t x0, int32_t y0, int32_t x1, int32_t y1, double* fb_out,
-                   double* per_sample_out, uint64_t* stats) {
+static void render_impl(const oracle_scene* s, const double* camera, int32_t W, int32_t sqrt_spp, int32_t max_depth,
+                        uint64_t seed, int32_t x0, int32_t y0, int32_t x1, int32_t y1, double* fb_out,
+                        double* per_sample_out, uint64_t* stats, bool unidirectional) {
     Camera cam = unpack_camera(camera);
     Stats st;
     memset(&st, 0, sizeof st);
@@ -729,7 +812,8 @@ void oracle_render(const oracle_scene* s, const double* camera, int32_t W, int32
                     rng.st.key = orng_stream_key(seed, (uint64_t)j * W + i, (uint64_t)s_j * sqrt_spp + s_i);
                     rng.st.counter = 0;
                     Ray r = get_ray(cam, i, j, s_i, s_j, recip_sqrt_spp, rng);
-                    V3 c = bidirectional_color(*s, cam, lights, r, max_depth, rng, st, camera_path, light_path);
+                    V3 c = unidirectional ? path_trace_color(*s, cam, lights, r, max_depth, rng, st)
+                                          : bidirectional_color(*s, cam, lights, r, max_depth, rng, st, camera_path, light_path);
                     pixel_color = add(pixel_color, c);
                     if (per_sample_out) {
                         per_sample_out[4 * sm] = c.x; per_sample_out[4 * sm + 1] = c.y; per_sample_out[4 * sm + 2] = c.z;
@@ -743,6 +827,19 @@ void oracle_render(const oracle_scene* s, const double* camera, int32_t W, int32
         }
     }
     if (stats) export_stats(st, *s, rng, stats);
+}
+
+void oracle_render(const oracle_scene* s, const double* camera, int32_t W, int32_t sqrt_spp, int32_t max_depth,
+                   uint64_t seed, int32_t x0, int32_t y0, int32_t x1, int32_t y1, double* fb_out,
+                   double* per_sample_out, uint64_t* stats) {
+    render_impl(s, camera, W, sqrt_spp, max_depth, seed, x0, y0, x1, y1, fb_out, per_sample_out, stats, false);
+}
+
+// the same loop with camera::path_trace_color as the estimator (camera.h:245-253 when `lights` is no triangle_collection)
+void oracle_render_unidirectional(const oracle_scene* s, const double* camera, int32_t W, int32_t sqrt_spp, int32_t max_depth,
+                                  uint64_t seed, int32_t x0, int32_t y0, int32_t x1, int32_t y1, double* fb_out,
+                                  uint64_t* stats) {
+    render_impl(s, camera, W, sqrt_spp, max_depth, seed, x0, y0, x1, y1, fb_out, nullptr, stats, true);
 }
 
 void oracle_render_serial_mt(const oracle_scene* s, const double* camera, int32_t W, int32_t H, int32_t sqrt_spp,

@@ -64,6 +64,12 @@ void oracle_render(const oracle_scene* s, const double* camera, int32_t W, int32
                    uint64_t seed, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
                    double* fb_out, double* per_sample_out, uint64_t* stats);
 
+/* The same loop with camera::path_trace_color (src/camera.h:255-292) as the estimator: what ray_color selects when
+ * `lights` is not a triangle_collection (camera.h:245-253).  stats as above (no shadow rays / pairs). */
+void oracle_render_unidirectional(const oracle_scene* s, const double* camera, int32_t W, int32_t sqrt_spp,
+                                  int32_t max_depth, uint64_t seed, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
+                                  double* fb_out, uint64_t* stats);
+
 /* Same loop over the whole W x H image on ONE serial default-seeded mt19937
  * (the unmodified reference's generator, src/main.h:28-32) - pins the restatement
  * against the unshimmed reference. */

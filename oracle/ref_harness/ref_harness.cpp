@@ -287,8 +287,11 @@ int main(int argc, char** argv) {
     }
 
 #ifndef HARNESS_NO_SHIM
-    if (op == "render" || op == "samples") {
+    if (op == "render" || op == "samples" || op == "render_uni") {
         // argv: seed x0 y0 x1 y1 out.bin [stats.bin]
+        // render_uni: the unidirectional estimator, camera::path_trace_color (src/camera.h:255-292), which
+        // ray_color only selects when `lights` is not a triangle_collection (camera.h:245-253)
+        const bool unidirectional = (op == "render_uni");
         uint64_t seed = strtoull(argv[3], nullptr, 10);
         int x0 = atoi(argv[4]), y0 = atoi(argv[5]), x1 = atoi(argv[6]), y1 = atoi(argv[7]);
         const int W = cam.image_width;
@@ -306,7 +309,8 @@ int main(int argc, char** argv) {
                             orng_stream_key(seed, (uint64_t)j * W + i, (uint64_t)s_j * cam.sqrt_spp + s_i);
                         harness_rng().stream.counter = 0;
                         ray r = cam.get_ray(i, j, s_i, s_j);
-                        color c = cam.ray_color(r, cam.max_depth, *b.bvh, lights);
+                        color c = unidirectional ? cam.path_trace_color(r, cam.max_depth, *b.bvh, lights)
+                                                 : cam.ray_color(r, cam.max_depth, *b.bvh, lights);
                         pixel_color += c;
                         if (per_sample) {
                             out.push_back(c[0]); out.push_back(c[1]); out.push_back(c[2]);

@@ -142,11 +142,41 @@ def golden_for(name, scene, tmp, *, seed, n_rays=0, n_pairs=0, crop=None, sample
     return g, spath
 
 
+def golden_unidirectional(name, scene, tmp, *, seed):
+    """camera::path_trace_color (src/camera.h:255-292) driven directly for every sample of the frame."""
+    spath = os.path.join(tmp, name + ".scene")
+    blob = scene.to_bytes()
+    with open(spath, "wb") as f:
+        f.write(blob)
+    o = lambda s: os.path.join(tmp, name + "." + s)
+    run(HARNESS, spath, "camera", o("cam"))
+    cam = rd(o("cam"))
+    W, H = scene.camera.image_width, int(cam[12])
+    run(HARNESS, spath, "render_uni", seed, 0, 0, W, H, o("fb"), o("st"))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                        scene_sha256=np.frombuffer(hashlib.sha256(blob).digest(), dtype=np.uint8),
+                        render_seed=np.array([seed], dtype=np.uint64), framebuffer=rd(o("fb")).reshape(H, W, 3),
+                        render_stats=rd(o("st")).astype(np.uint64))
+    print(name, "ok")
+
+
+def unidirectional_fixtures(tmp):
+    golden_unidirectional("uni_cornell24", scenes.cornell_box(32, 16, 10), tmp, seed=4)
+    golden_unidirectional("uni_showcase", scenes.materials_showcase(32, 9, 8), tmp, seed=6)
+    golden_unidirectional("uni_nolight", scenes.no_light_room(16, 4, 5), tmp, seed=8)      # lights = the whole world
+    golden_unidirectional("uni_cornell_d1", scenes.cornell_box(16, 4, 1), tmp, seed=2)
+
+
 def main():
     for b in (HARNESS, HARNESS_GLIBC, HARNESS_NOSHIM):
         if not os.path.exists(b):
             sys.exit("missing %s - run `make -C oracle ref` first" % b)
+    if "--only-unidirectional" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            unidirectional_fixtures(tmp)
+        return
     with tempfile.TemporaryDirectory() as tmp:
+        unidirectional_fixtures(tmp)
         # config-2 geometry, small image
         g, spath = golden_for("cornell24", scenes.cornell_box(48, 16, 10), tmp, seed=0, n_rays=2048, n_pairs=1024,
                               sample_crop=(20, 20, 28, 28), glibc=True)

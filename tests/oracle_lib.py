@@ -84,6 +84,14 @@ class OracleScene:
                                int(seed), x0, y0, x1, y1, fb, smp.ctypes.data if per_sample else None, stats)
         return fb, stats, smp
 
+    def render_unidirectional(self, cam15, W, sqrt_spp, max_depth, seed, rect):
+        x0, y0, x1, y1 = [int(v) for v in rect]
+        fb = np.zeros((y1 - y0, x1 - x0, 3))
+        stats = np.zeros(10, dtype=np.uint64)
+        self.lib.oracle_render_unidirectional(self.h, np.ascontiguousarray(cam15, dtype=np.float64), W, sqrt_spp, max_depth,
+                                              int(seed), x0, y0, x1, y1, fb, stats)
+        return fb, stats
+
     def render_serial_mt(self, cam15, W, H, sqrt_spp, max_depth):
         fb = np.zeros((H, W, 3))
         stats = np.zeros(10, dtype=np.uint64)
@@ -110,6 +118,8 @@ class Oracle:
         lib.oracle_visible.argtypes = [C.c_void_p, _d, C.c_uint64, _d]
         lib.oracle_render.argtypes = [C.c_void_p, _d, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, _d, C.c_void_p, _u64]
+        lib.oracle_render_unidirectional.argtypes = [C.c_void_p, _d, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32,
+                                                     C.c_int32, C.c_int32, C.c_int32, _d, _u64]
         lib.oracle_render_serial_mt.argtypes = [C.c_void_p, _d, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _d, _u64]
         lib.oracle_colors_to_rgb8.argtypes = [_d, C.c_int32, C.c_int32, C.c_int32, _u8]
         lib.oracle_sincos_array.argtypes = [_d, C.c_uint64, _d, _d]

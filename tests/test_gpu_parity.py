@@ -312,3 +312,30 @@ def test_command_line_renderer_end_to_end(tmp_path, oracle):
                                           (0, 0, cam.image_width, cam.image_height))
     want = capi.colors_to_rgb8(ofb, cam.sqrt_spp ** 2)
     assert img.shape == want.shape and (img == want).all()
+
+
+UNI_CASES = {
+    "uni_cornell24": lambda s: s.cornell_box(32, 16, 10),
+    "uni_showcase": lambda s: s.materials_showcase(32, 9, 8),
+    "uni_nolight": lambda s: s.no_light_room(16, 4, 5),
+    "uni_cornell_d1": lambda s: s.cornell_box(16, 4, 1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(UNI_CASES))
+def test_unidirectional_estimator_matches_reference(name, scenes, ctx):
+    """BDPT_RENDER_UNIDIRECTIONAL = camera::path_trace_color (src/camera.h:255-292), bit for bit against the
+    reference's own function, including its BvhStats counters and the number of random draws."""
+    flat = UNI_CASES[name](scenes)
+    g = load_golden(name)
+    assert hashlib.sha256(flat.to_bytes()).digest() == bytes(g["scene_sha256"])
+    sc = ctx.scene(flat)
+    cam = capi.camera_initialize(flat.camera)
+    seed = int(g["render_seed"][0])
+    fb = sc.render(cam, seed=seed, unidirectional=True)
+    assert_bit_equal(fb, g["framebuffer"], "unidirectional framebuffer")
+    fb2, st = sc.render(cam, seed=seed, unidirectional=True, want_stats=True)
+    assert_bit_equal(fb2, g["framebuffer"], "unidirectional framebuffer, counting mode")
+    want = [int(v) for v in g["render_stats"]]
+    assert [st.rays_traced, st.aabb_tests, st.aabb_hits, st.bvh_node_visits, st.triangle_tests, st.triangle_hits] == want[:6]
+    assert st.rng_draws == want[7]

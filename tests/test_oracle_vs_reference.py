@@ -135,3 +135,26 @@ def test_glibc_libm_noise_floor():
     rel_l2 = np.linalg.norm(a - b) / np.linalg.norm(a)
     assert differing < 0.05
     assert rel_l2 < 2e-3
+
+
+UNI_CASES = {
+    "uni_cornell24": lambda s: s.cornell_box(32, 16, 10),
+    "uni_showcase": lambda s: s.materials_showcase(32, 9, 8),
+    "uni_nolight": lambda s: s.no_light_room(16, 4, 5),
+    "uni_cornell_d1": lambda s: s.cornell_box(16, 4, 1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(UNI_CASES))
+def test_unidirectional_estimator(name, scenes, oracle):
+    """camera::path_trace_color (src/camera.h:255-292) of the reference, driven for every sample of the frame."""
+    flat = UNI_CASES[name](scenes)
+    g = load_golden(name)
+    assert hashlib.sha256(flat.to_bytes()).digest() == bytes(g["scene_sha256"]), "scene builder drifted from the fixture"
+    cam15, H, sqrt_spp = oracle.camera_initialize(flat.camera)
+    W = flat.camera.image_width
+    fb, stats = oracle.scene(flat).render_unidirectional(cam15, W, sqrt_spp, flat.camera.max_depth, int(g["render_seed"][0]),
+                                                         (0, 0, W, H))
+    assert_bit_equal(fb, g["framebuffer"], "framebuffer sums")
+    assert np.array_equal(stats[:6], g["render_stats"][:6]), "BvhStats"
+    assert stats[7] == g["render_stats"][7], "RNG draw total"
