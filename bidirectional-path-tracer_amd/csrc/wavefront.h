@@ -38,6 +38,8 @@ constexpr int kWideStackDepth = 40;
 constexpr int kQuadStackEntries = 64;
 
 constexpr uint32_t kCntEyeHit = 1u << 24, kCntLightHit = 1u << 25, kCntLightValid = 1u << 26;
+// the eye subpath stored at least one vertex that can form a non-zero connection (non-delta, not on an emitter)
+constexpr uint32_t kCntEyeConnectable = 1u << 27;
 
 struct WfBatch {
     uint64_t seed;

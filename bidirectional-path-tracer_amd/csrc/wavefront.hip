@@ -543,6 +543,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
                 const uint32_t ne = cnt & 0xFFFu, nl = (cnt >> 12) & 0xFFFu;
                 slot_store(wb, slot).put(EYE ? (int)ne : depth + (int)nl, bo.vx);
                 cnt += EYE ? 1u : (1u << 12);
+                if (EYE && !(bo.vx.info & kVtxIsLight)) cnt |= kCntEyeConnectable;
                 if (STATS) n_stored++;
             }
             wb.counts[slot] = cnt;
@@ -589,9 +590,18 @@ __global__ __launch_bounds__(kStageBlock) void k_gen_light(SceneDev sc, GpuCamer
             sample_emitter(sc, depth, rng, em);
             wb.ctr[slot] = rng.counter;
             if (!em.valid) continue;
+            const uint32_t cnt = wb.counts[slot];
+            // A light subpath only matters through its connections (camera.h:316-320), and a pair contributes
+            // zero when the eye vertex is delta (camera.h:441) or on an emitter (zero BSDF, material.h:35-37):
+            // without a connectable eye vertex the subpath is not traced and nothing of it is stored.  Its
+            // random draws come after everything else the sample draws, so skipping them changes nothing.
+            if (!(cnt & kCntEyeConnectable)) {
+                wb.counts[slot] = cnt | kCntLightValid | kCntLightHit;
+                continue;
+            }
             slot_store(wb, slot).put(depth, em.ev);
             if (STATS) n_stored++;
-            wb.counts[slot] = wb.counts[slot] | kCntLightValid | kCntLightHit | (1u << 12);
+            wb.counts[slot] = cnt | kCntLightValid | kCntLightHit | (1u << 12);
             if (em.has_ray && depth - 1 > 0) {
                 cont[j] = true;
                 wb.ray[slot] = em.o.x; wb.ray[ns + slot] = em.o.y; wb.ray[2 * ns + slot] = em.o.z;
