@@ -771,8 +771,17 @@ __global__ __launch_bounds__(kBlock) void k_resolve(GpuCamera cam, WfBuffers wb,
         const uint32_t q = (uint32_t)b.first_pixel + (uint32_t)p;
         if (q >= (uint32_t)b.n_owned) continue;
         const double* src = wb.result + (uint64_t)ch * wb.ns + p;
+        // the additions are sequential (the reference's order); the loads are not: sixteen in flight at a time
         double acc = 0.0;
-        for (int s = 0; s < spp; s++) acc = acc + src[(uint64_t)s * b.pixels_stride];
+        int s = 0;
+        for (; s + 16 <= spp; s += 16) {
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[q] = src[(uint64_t)(s + q) * b.pixels_stride];
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc = acc + v[q];
+        }
+        for (; s < spp; s++) acc = acc + src[(uint64_t)s * b.pixels_stride];
         const uint32_t row = q / (uint32_t)b.row_w;
         const int j = b.rows[row];
         const int i = b.x0 + (int)(q - row * (uint32_t)b.row_w);
