@@ -143,6 +143,9 @@ def main():
         cpu_worker(args)
         return
 
+    if os.environ.get("BDPT_BENCH_WATCHDOG"):       # dump every thread's stack if the run takes longer than this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BDPT_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,10 +166,17 @@ def main():
     capi = importlib.import_module(PKG + ".capi")
     distributed = importlib.import_module(PKG + ".distributed")
 
+    # one process per GPU; BDPT_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 path
+    backend = os.environ.get("BDPT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     ctx = capi.Context(local_rank)
     scene = ctx.scene(flat)

@@ -360,7 +360,7 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     if (scene->ctx != ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "scene belongs to another context");
     if (cam->image_width <= 0 || cam->image_height <= 0) return fail(BDPT_ERR_INVALID_ARGUMENT, "empty image");
     if (cam->sqrt_spp < 1) return fail(BDPT_ERR_INVALID_ARGUMENT, "sqrt_spp must be at least 1");
-    if (cam->max_depth < 0 || cam->max_depth > 4096) return fail(BDPT_ERR_INVALID_ARGUMENT, "max_depth out of range");
+    if (cam->max_depth < 0 || cam->max_depth > 4095) return fail(BDPT_ERR_INVALID_ARGUMENT, "max_depth out of range");   // vertex counts are kept in 12 bits
     if ((int64_t)cam->sqrt_spp * cam->sqrt_spp > (1 << 24)) return fail(BDPT_ERR_INVALID_ARGUMENT, "too many samples per pixel");
 
     const int W = cam->image_width, H = cam->image_height;

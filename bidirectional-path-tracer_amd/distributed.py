@@ -36,5 +36,11 @@ def render_frame(render_shard: Callable, fb, rank: int, world: int, shard_rows: 
         fb.zero_()
     render_shard(fb, shard)
     if world > 1:
-        dist.all_reduce(fb, op=dist.ReduceOp.SUM)
+        if getattr(fb, "is_cuda", False) and dist.get_backend() == "gloo":
+            # rehearsal on a machine without RCCL peers: gloo reduces a host copy
+            host = fb.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            fb.copy_(host)
+        else:
+            dist.all_reduce(fb, op=dist.ReduceOp.SUM)
     return fb
