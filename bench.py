@@ -50,6 +50,10 @@ WORKLOADS = {
                     "Cornell box (24 triangles, diffuse + emissive), 512x512, 256 spp, max depth 10"),
     "glass-of-water-1080p-16spp": ("glass_of_water_standin", dict(image_width=1920, image_height=1080, samples_per_pixel=16, max_depth=12),
                                    "glass-of-water stand-in, 1920x1080, 16 spp, max depth 12 (profiling size)"),
+    "sphere-lattice-10m-4096": ("sphere_lattice", dict(n_side=22, image_width=4096, samples_per_pixel=64, max_depth=10),
+                                "22^3 lambertian spheres of 960 triangles (10.2 M triangles) over a floor, one emissive quad, 4096x4096, 64 spp, max depth 10"),
+    "sphere-lattice-1m-1024": ("sphere_lattice", dict(n_side=10, image_width=1024, samples_per_pixel=64, max_depth=10),
+                               "10^3 lambertian spheres (0.96 M triangles), 1024x1024, 64 spp, max depth 10"),
     "glass-of-water-256": ("glass_of_water_standin", dict(image_width=256, image_height=256, samples_per_pixel=16, max_depth=4),
                            "glass-of-water stand-in, 256x256, 16 spp, max depth 4"),
 }

@@ -101,8 +101,10 @@ class FlatScene:
         out = [b"BDPTSCN1", struct.pack("<4I", len(self.materials), self.n_triangles, len(self.lights), 0)]
         for m in self.materials:
             out.append(struct.pack("<2i5d", m.type, 0, m.rgb[0], m.rgb[1], m.rgb[2], m.fuzz, m.ior))
-        for v, mat in zip(self.vertices, self.tri_material):
-            out.append(struct.pack("<9d2i", *v, mat, 0))
+        rec = np.zeros(self.n_triangles, dtype=[("v", "<f8", 9), ("m", "<i4"), ("pad", "<i4")])
+        rec["v"] = self.vertex_array()
+        rec["m"] = self.tri_material_array()
+        out.append(rec.tobytes())
         lights = list(self.lights) + ([0] if len(self.lights) % 2 else [])
         out.append(struct.pack("<%dI" % len(lights), *lights))
         c = self.camera
@@ -254,6 +256,51 @@ def no_light_room(image_width: int = 24, samples_per_pixel: int = 4, max_depth: 
                       max_depth=max_depth, background=(0.7, 0.8, 1.0), vfov=50.0, lookfrom=(0, 3, -8),
                       lookat=(0, 1, 0), vup=(0, 1, 0), file_name="nolight.png")
     return s
+
+
+def sphere_lattice(n_side: int = 22, image_width: int = 4096, samples_per_pixel: int = 64, max_depth: int = 10) -> FlatScene:
+    """Many-triangle scene: the loader's 16 x 32 sphere tessellation (960 triangles) replicated on an
+    n_side^3 grid of lambertian spheres over a floor, under one emissive quad; flattened, as the reference has no
+    instancing on this path.  n_side = 22 gives 10.2 M triangles."""
+    s = FlatScene()
+    grey = s.add_material(Material(LAMBERTIAN, (.6, .6, .6)))
+    palette = [s.add_material(Material(LAMBERTIAN, c)) for c in
+               ((.75, .25, .25), (.25, .75, .25), (.25, .25, .75), (.7, .7, .2), (.2, .7, .7), (.7, .2, .7))]
+    light = s.add_material(Material(DIFFUSE_LIGHT, (40.0, 40.0, 40.0)))
+    extent = 3.0 * n_side
+    add_quad_triangles(s, (-extent, -1.5, -extent), (3 * extent, 0, 0), (0, 0, 3 * extent), grey)
+    add_quad_triangles(s, (0.25 * extent, 1.6 * extent, 0.25 * extent), (0.5 * extent, 0, 0), (0, 0, 0.5 * extent), light)
+    unit = FlatScene()
+    m0 = unit.add_material(Material(LAMBERTIAN, (0, 0, 0)))
+    add_uv_sphere(unit, (0.0, 0.0, 0.0), 1.0, m0)
+    base = np.array(unit.vertices, dtype=np.float64).reshape(-1, 3, 3)              # 960 x 3 vertices x xyz
+    idx = np.arange(n_side, dtype=np.float64) * 3.0
+    cx, cy, cz = np.meshgrid(idx, idx, idx, indexing="ij")
+    centers = np.stack([cx.ravel(), cy.ravel(), cz.ravel()], axis=1)                 # n^3 x 3
+    verts = (base[None, :, :, :] + centers[:, None, None, :]).reshape(-1, 9)
+    mats = np.repeat(np.array(palette, dtype=np.int64)[np.arange(len(centers)) % len(palette)], len(base))
+    s.vertices = np.concatenate([np.array(s.vertices, dtype=np.float64).reshape(-1, 9), verts]).tolist() if n_side <= 4 else \
+        _Rows(np.concatenate([np.array(s.vertices, dtype=np.float64).reshape(-1, 9), verts]))
+    s.tri_material = list(s.tri_material) + mats.tolist()
+    s.camera = Camera(aspect_ratio=1.0, image_width=image_width, samples_per_pixel=samples_per_pixel, max_depth=max_depth,
+                      background=(0.02, 0.02, 0.03), vfov=40.0, lookfrom=(-1.2 * extent, 1.4 * extent, -1.6 * extent),
+                      lookat=(0.5 * extent, 0.3 * extent, 0.5 * extent), vup=(0, 1, 0), file_name="sphere_lattice.png")
+    return s
+
+
+class _Rows:
+    """Vertex table kept as one array (large scenes); behaves like the list of 9-float rows FlatScene expects."""
+    def __init__(self, a):
+        self.a = np.ascontiguousarray(a, dtype=np.float64)
+
+    def __len__(self):
+        return len(self.a)
+
+    def __iter__(self):
+        return iter(self.a)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.a if dtype is None else self.a.astype(dtype, copy=False)
 
 
 # ------------------------------------------------------------------------------- stand-ins for the shipped scenes

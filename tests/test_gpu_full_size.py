@@ -57,3 +57,23 @@ def test_glass_of_water_1080p_1024spp_depth12(scenes, ctx, oracle):
     assert flat.camera.image_width == 1920 and flat.camera.samples_per_pixel == 1024 and flat.camera.max_depth == 12
     check_full_size(flat, ctx, oracle, lambda W, H: [(int((a + 0.5) * W / 6), int((b + 0.5) * H / 4)) for a in range(6) for b in range(4)],
                     (900, 500, 916, 504))
+
+
+def test_million_triangle_lattice(scenes, ctx, oracle):
+    """Many-triangle scene (0.96 M triangles: deep hierarchies, nothing fits LDS): pixels against the oracle, and the
+    two GPU implementations against each other."""
+    flat = scenes.sphere_lattice(10, 96, 16, 10)
+    assert flat.n_triangles == 960 * 1000 + 4
+    sc = ctx.scene(flat)
+    info = sc.info()
+    assert info.n_triangles == flat.n_triangles
+    cam = capi.camera_initialize(flat.camera)
+    W, H = cam.image_width, cam.image_height
+    whole = sc.render(cam, seed=1)
+    crop = (40, 40, 56, 48)
+    mk = sc.render(cam, seed=1, rect=crop, megakernel=True)
+    assert (bits(mk[40:48, 40:56]) == bits(whole[40:48, 40:56])).all()
+    osc = oracle.scene(flat)
+    ofb, _, _ = osc.render(cam.as_array(), W, cam.sqrt_spp, cam.max_depth, 1, (20, 60, 76, 64))
+    assert (bits(ofb) == bits(whole[60:64, 20:76])).all()
+    sc.close()
