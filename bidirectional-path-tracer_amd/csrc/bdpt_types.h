@@ -35,23 +35,8 @@ struct GpuTri {
 };
 static_assert(sizeof(GpuTri) == 80, "GpuTri must stay 80 bytes");
 
-// The same tree in "wide" form for ORDERED traversal with a small per-lane stack: one 128-byte
-// record (a full cache line) per interior bvh_node holding the boxes of BOTH children, so one
-// fetch decides which child is nearer and whether the farther one is needed at all.  The boxes
-// are the reference's FP64 node boxes, bit for bit, so a box test here is the test the reference
-// makes when it visits that child (src/acceleration/bvh.h:52).  Child reference: >= 0 index of an
-// interior record; < 0 a leaf, ~ref = (first << 2) | (count - 1): `count` triangles starting at
-// position `first` of the triangle table sorted in the reference's left-to-right leaf order.
-struct GpuWideNode {
-    double lo0[3], hi0[3];
-    double lo1[3], hi1[3];
-    int32_t child0, child1;
-    int32_t pad[6];
-};
-static_assert(sizeof(GpuWideNode) == 128, "GpuWideNode must stay 128 bytes");
-
 // Closest-hit queries do not depend on the shape of the tree (the answer is the nearest accepted
-// triangle, ties resolved by the reference's leaf order), so they use a separate hierarchy: a binned
+// triangle, ties resolved by the reference's leaf order), so the wavefront kernels use a separate hierarchy: a binned
 // surface-area-heuristic tree collapsed to four children per record.  128-byte records, child boxes in
 // FP32 rounded OUTWARD (a box here always contains the padded FP64 box of everything below it, so
 // culling is conservative), leaves of up to four triangles.  Child reference: >= 0 index of an interior
@@ -65,10 +50,9 @@ struct GpuQuadNode {
 static_assert(sizeof(GpuQuadNode) == 128, "GpuQuadNode must stay 128 bytes");
 constexpr int32_t kQuadEmpty = (int32_t)0x80000000;
 
-// Records [0, kLdsTop*) of the two hierarchies are the levels nearest the root in breadth-first order; the
-// traversal kernels copy a prefix of them into LDS, so only the deeper visits go to L1/L2.
+// Records [0, kLdsTopQuadNodes) are the levels nearest the root in breadth-first order; the traversal kernels
+// copy a prefix of them into LDS, so only the deeper visits go to L1/L2.
 constexpr uint32_t kLdsTopQuadNodes = 1024;
-constexpr uint32_t kLdsTopWideNodes = 1024;
 
 // Read once per accepted hit / light sample: unit normal and area (triangle.h:26-29).
 struct GpuTriAux {
@@ -97,9 +81,9 @@ struct GpuCamera {
 struct SceneDev {
     const GpuNode* nodes;
     const GpuTri* tris;
-    const GpuWideNode* wnodes;      // ordered-traversal form of the same tree
+    const uint32_t* node_parent;    // parent of every node of `nodes` (kEndOfTree for the root)
     const GpuTri* stris;            // triangles in leaf order; `pad` holds the original triangle id
-    uint32_t n_wnodes;
+    const uint32_t* sleaf;          // per entry of `stris`: the node of `nodes` that holds the triangle
     const GpuQuadNode* xnodes;      // closest-hit hierarchy (surface-area heuristic, four children, FP32 boxes)
     const GpuTri* xtris;            // its triangles in its own leaf order; `pad` = position in `stris`
     uint32_t n_xnodes;

@@ -182,7 +182,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const size_t vslots = 2 * (size_t)(depth > 0 ? depth : 1);
     const uint32_t vis_words = (uint32_t)((depth > 0 ? depth : 1) + 63) / 64;
     const size_t shadow_per_slot = (size_t)(depth > 0 ? depth : 1);
-    if ((int)scene->host.tree_depth > kWideStackDepth || (int)scene->host.sah_stack + 3 > kQuadStackEntries)
+    if ((int)scene->host.sah_stack + 3 > kQuadStackEntries)
         return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     if (n_owned >= ((int64_t)1 << 31)) return fail(BDPT_ERR_UNSUPPORTED, "more than 2^31 pixels in one call");
     // bytes of state per sample slot
@@ -238,11 +238,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     }
 
     WfLaunchCfg cfg;
-    {   // per traversal kernel: its own node table + its own triangle order
-        const size_t shadow_bytes = (size_t)scene->dev.n_wnodes * sizeof(GpuWideNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
-        const size_t extend_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuQuadNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
-        cfg.lds_bytes = shadow_bytes > extend_bytes ? shadow_bytes : extend_bytes;
-    }
+    cfg.lds_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuQuadNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
     cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
     if (!cfg.lds_scene) cfg.lds_bytes = 0;
     cfg.trav_block = env_int("BDPT_WF_TRAV_BLOCK", 256);
@@ -498,9 +494,10 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     // one device allocation, tables at 256-byte aligned offsets
     size_t off_nodes = 0;
     size_t off_tris = off_nodes + align256(h.nodes.size() * sizeof(GpuNode));
-    size_t off_wn = off_tris + align256(h.tris.size() * sizeof(GpuTri));
-    size_t off_st = off_wn + align256(h.wnodes.size() * sizeof(GpuWideNode));
-    size_t off_xn = off_st + align256(h.stris.size() * sizeof(GpuTri));
+    size_t off_np = off_tris + align256(h.tris.size() * sizeof(GpuTri));
+    size_t off_st = off_np + align256(h.node_parent.size() * sizeof(uint32_t));
+    size_t off_sl = off_st + align256(h.stris.size() * sizeof(GpuTri));
+    size_t off_xn = off_sl + align256(h.sleaf.size() * sizeof(uint32_t));
     size_t off_xt = off_xn + align256(h.xnodes.size() * sizeof(GpuQuadNode));
     size_t off_aux = off_xt + align256(h.xtris.size() * sizeof(GpuTri));
     size_t off_mats = off_aux + align256(h.aux.size() * sizeof(GpuTriAux));
@@ -515,8 +512,9 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     struct { size_t off; const void* src; size_t bytes; } parts[] = {
         {off_nodes, h.nodes.data(), h.nodes.size() * sizeof(GpuNode)},
         {off_tris, h.tris.data(), h.tris.size() * sizeof(GpuTri)},
-        {off_wn, h.wnodes.data(), h.wnodes.size() * sizeof(GpuWideNode)},
+        {off_np, h.node_parent.data(), h.node_parent.size() * sizeof(uint32_t)},
         {off_st, h.stris.data(), h.stris.size() * sizeof(GpuTri)},
+        {off_sl, h.sleaf.data(), h.sleaf.size() * sizeof(uint32_t)},
         {off_xn, h.xnodes.data(), h.xnodes.size() * sizeof(GpuQuadNode)},
         {off_xt, h.xtris.data(), h.xtris.size() * sizeof(GpuTri)},
         {off_aux, h.aux.data(), h.aux.size() * sizeof(GpuTriAux)},
@@ -531,9 +529,9 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     SceneDev& d = s->dev;
     d.nodes = reinterpret_cast<const GpuNode*>(base + off_nodes);
     d.tris = reinterpret_cast<const GpuTri*>(base + off_tris);
-    d.wnodes = reinterpret_cast<const GpuWideNode*>(base + off_wn);
+    d.node_parent = reinterpret_cast<const uint32_t*>(base + off_np);
     d.stris = reinterpret_cast<const GpuTri*>(base + off_st);
-    d.n_wnodes = (uint32_t)h.wnodes.size();
+    d.sleaf = reinterpret_cast<const uint32_t*>(base + off_sl);
     d.xnodes = reinterpret_cast<const GpuQuadNode*>(base + off_xn);
     d.xtris = reinterpret_cast<const GpuTri*>(base + off_xt);
     d.n_xnodes = (uint32_t)h.xnodes.size();

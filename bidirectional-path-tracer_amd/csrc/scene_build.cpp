@@ -396,52 +396,28 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
         }
     }
 
-    // wide records for ordered traversal: interior nodes in pre-order, triangles in leaf order
+    // triangles in the reference's left-to-right leaf order (the tie-break key of closest-hit queries), and for
+    // each of them the bvh_node that holds it; parents of all nodes (visibility queries re-check the reference's
+    // own boxes from that node up to the root)
     {
-        std::vector<uint32_t> pos_of(n_tri, 0);
+        std::vector<uint32_t> node_of(n_tri, 0);
+        out.node_parent.assign(n_nodes, kEndOfTree);
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            const BuildNode& n = b.nodes[i];
+            if (n.left >= 0) { out.node_parent[n.left] = i; out.node_parent[n.right] = i; }
+            else { node_of[(uint32_t)~n.left] = i; node_of[(uint32_t)~n.right] = i; }
+        }
         out.stris.reserve(n_tri);
+        out.sleaf.reserve(n_tri);
         for (size_t k = 0; k < out.dfs_leaves.size(); k++) {
             const uint32_t id = out.dfs_leaves[k];
             if (k > 0 && out.dfs_leaves[k - 1] == id && (k & 1)) continue;      // second mention by a one-triangle node
-            pos_of[id] = (uint32_t)out.stris.size();
             GpuTri t = out.tris[id];
             t.pad = (int32_t)id;
             out.stris.push_back(t);
-        }
-        std::vector<int32_t> wide_index(n_nodes, -1);
-        int32_t n_wide = 0;
-        for (uint32_t i = 0; i < n_nodes; i++) if (b.nodes[i].left >= 0) wide_index[i] = n_wide++;
-        auto child_ref = [&](int32_t node) -> int32_t {
-            const BuildNode& n = b.nodes[node];
-            if (n.left >= 0) return wide_index[node];
-            const uint32_t t0 = (uint32_t)~n.left, t1 = (uint32_t)~n.right;
-            const uint32_t code = (pos_of[t0] << 2) | (t1 != t0 ? 1u : 0u);
-            return ~(int32_t)code;
-        };
-        const double inf = std::numeric_limits<double>::infinity();
-        if (n_wide == 0) {                      // the root's children are triangles: wrap it in one record
-            GpuWideNode w{};
-            for (int k = 0; k < 3; k++) { w.lo0[k] = b.nodes[0].box.lo[k]; w.hi0[k] = b.nodes[0].box.hi[k]; w.lo1[k] = inf; w.hi1[k] = -inf; }
-            w.child0 = child_ref(0);
-            w.child1 = ~(int32_t)0;
-            out.wnodes.push_back(w);
-        } else {
-            out.wnodes.resize(n_wide);
-            for (uint32_t i = 0; i < n_nodes; i++) {
-                const BuildNode& n = b.nodes[i];
-                if (n.left < 0) continue;
-                GpuWideNode w{};
-                const Box3& b0 = b.nodes[n.left].box;
-                const Box3& b1 = b.nodes[n.right].box;
-                for (int k = 0; k < 3; k++) { w.lo0[k] = b0.lo[k]; w.hi0[k] = b0.hi[k]; w.lo1[k] = b1.lo[k]; w.hi1[k] = b1.hi[k]; }
-                w.child0 = child_ref(n.left);
-                w.child1 = child_ref(n.right);
-                out.wnodes[wide_index[i]] = w;
-            }
+            out.sleaf.push_back(node_of[id]);
         }
     }
-
-    hoist_top_levels<2>(out.wnodes, kLdsTopWideNodes, [](GpuWideNode& w) { return &w.child0; });
 
     // closest-hit hierarchy over the same triangles (referenced by their position in `stris`)
     {

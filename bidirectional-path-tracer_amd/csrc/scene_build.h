@@ -15,7 +15,8 @@ namespace bdpt {
 struct HostScene {
     std::vector<GpuNode> nodes;          // pre-order (root first); links already threaded
     std::vector<GpuTri> tris;
-    std::vector<GpuWideNode> wnodes;     // interior nodes in pre-order, both child boxes per record
+    std::vector<uint32_t> node_parent;   // parent of every bvh_node (kEndOfTree for the root)
+    std::vector<uint32_t> sleaf;         // per entry of `stris`: the bvh_node that holds the triangle
     std::vector<GpuTri> stris;           // triangles in leaf order (pad = original id)
     std::vector<GpuQuadNode> xnodes;     // closest-hit hierarchy (binned SAH, four children per record)
     std::vector<GpuTri> xtris;           // its triangles in leaf order (pad = position in stris)

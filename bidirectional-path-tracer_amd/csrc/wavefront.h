@@ -32,8 +32,6 @@ struct WfBuffers {
     uint32_t vis_words;
 };
 
-// per-lane stack of the ordered walk (one entry per tree level at most)
-constexpr int kWideStackDepth = 40;
 // entries of the closest-hit walk's stack (up to three pushes per level of the four-wide tree)
 constexpr int kQuadStackEntries = 64;
 

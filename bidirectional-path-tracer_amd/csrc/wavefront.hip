@@ -121,21 +121,23 @@ __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb,
 }
 
 // ------------------------------------------------------------------ persistent traversal
-// Ordered (near child first) walk over the wide records with a small per-lane stack.
+// Ordered (near child first) walk over the four-wide records with a small per-lane stack.
 //
-// Why a different visiting order still returns the reference's answer:
-//  * every box test is the reference's test (same FP64 box, same slab arithmetic, the running
-//    closest t as upper bound), and a triangle is accepted by the reference's inclusive interval
-//    test (triangle.h:63);
-//  * shadow rays: the upper bound never changes before the first accepted triangle, so the set of
-//    boxes that pass - and therefore whether ANY triangle is accepted - does not depend on the order;
-//  * closest-hit rays: the reference keeps, among equal t, the triangle it visits last (bvh.h:55-56),
-//    i.e. the one later in its left-to-right leaf order; triangles are stored in that order, so the
-//    tie is broken by position.  Culling against a closer bound found earlier only removes boxes that
-//    lie entirely behind that bound.
-//  * the root's own box (bvh.h:52 at the root) is not tested separately: it contains both child
-//    boxes, and the slab arithmetic is monotone, so a ray that passes a child box passes the root box.
-constexpr int kStackDepth = kWideStackDepth;
+// Why a different hierarchy and visiting order still return the reference's answers:
+//  * a triangle is accepted by the reference's own inclusive interval test (triangle.h:63) in the
+//    reference's FP64 arithmetic; the boxes of this hierarchy contain everything below them with a margin,
+//    so culling never loses a triangle that would be accepted;
+//  * closest-hit rays: the reference keeps, among equal t, the triangle it visits last (bvh.h:55-56), i.e.
+//    the one later in its left-to-right leaf order; the tie is broken by that position (tr.pad);
+//  * visibility rays (camera.h:425-438): the reference reports "blocked" iff some triangle accepts AND it
+//    gets to test that triangle, i.e. the box of every bvh_node above it passes aabb::hit with the
+//    unchanged interval [0.001, max_t] (the bound only shrinks after the first acceptance).  That second
+//    condition matters: the far end point lies ON a surface at t = max_t, and a node box whose face
+//    coincides with that surface is entered at t = max_t too - rounding decides, and the reference never
+//    tests the triangle when the box loses.  So a triangle accepted at an end of the interval counts only if
+//    reference_reaches() confirms the reference's own boxes from its node up to the root, in the reference's
+//    arithmetic.  (Both kinds of query share one residual assumption: a box is not lost to rounding when the
+//    ray is inside it for less than ~1e-12 of its length around the hit point.)
 constexpr int kQuadStackDepth = kQuadStackEntries;
 constexpr int32_t kPop = (int32_t)0x80000000;   // neither an interior index (>= 0) nor a leaf reference
 
@@ -242,6 +244,17 @@ BDPT_DEV void sort2(double& a, double& b) {
     a = lo; b = hi;
 }
 
+// aabb::hit (aabb.h:41-66) of every bvh_node from `node` up to the root, with the interval [0.001, max_t]
+BDPT_DEV bool reference_reaches(const SceneDev& sc, uint32_t node, V3 o, double ix, double iy, double iz, double max_t) {
+    for (uint32_t n = node; n != kEndOfTree; n = sc.node_parent[n]) {
+        const GpuNode nd = sc.nodes[n];
+        double lo, hi;
+        slab(nd.lo, nd.hi, o, ix, iy, iz, max_t, lo, hi);
+        if (hi <= lo) return false;
+    }
+    return true;
+}
+
 // One loop iteration is EITHER one interior record for every lane that stands at one, OR one triangle
 // for every lane that stands at a leaf: a wave executes both sides of a divergent branch one after the
 // other, so mixing the two in one iteration would run the (long) triangle test for a handful of lanes
@@ -249,7 +262,7 @@ BDPT_DEV void sort2(double& a, double& b) {
 // has an interior record left).  SHADOW: rays come from the shadow queue, the walk stops at the first
 // accepted triangle and a clear ray sets its pair's visibility bit.
 template <bool SHADOW, bool STATS, class Mem>
-BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffers& wb, const uint32_t* queue, uint32_t count,
+BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, uint32_t count,
                              uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk,
                              const int kLeafThreshold, const double coord_bound) {
     bool has = false;
@@ -257,14 +270,11 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
     int32_t cur = kPop;                 // interior record to visit next (when leaf_left == 0)
     uint32_t leaf_next = 0, leaf_left = 0;   // triangles of the current leaf still to test
     int sp = 0;
-    // SHADOW: (record, entry distance) pairs; closest hit: one 64-bit word per entry, see quad_entry()
-    int32_t stk_node[SHADOW ? kStackDepth : 1];
-    double stk_lo[SHADOW ? kStackDepth : 1];
-    double stk_quad[SHADOW ? 1 : kQuadStackDepth];
+    double stk_quad[kQuadStackDepth];   // one 64-bit word per entry, see quad_entry()
     unsigned long long tag = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     double ix = 0, iy = 0, iz = 0, closest = 0;
-    RayF32 rf = {};                     // closest hit only
+    RayF32 rf = {};
     HitLite h;
     h.t = 0; h.u = 0; h.v = 0; h.tri = -1;
     int32_t best_pos = -1;
@@ -305,7 +315,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
                     }
                     if (!SHADOW || tmax0 >= 0.0) {              // a negative max_t marks an unused queue entry
                         ix = 1.0 / d.x; iy = 1.0 / d.y; iz = 1.0 / d.z;       // aabb.h:48, once per ray
-                        if (!SHADOW) rf = ray_f32(o, ix, iy, iz, coord_bound);
+                        rf = ray_f32(o, ix, iy, iz, coord_bound);
                         closest = tmax0;
                         cur = 0;
                         leaf_left = 0;
@@ -331,22 +341,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
             if (has && leaf_left == 0) {
                 const auto nd = mem.wnode(cur);
                 if (STATS) n_records++;
-                if constexpr (SHADOW) {
-                    double lo0, hi0, lo1, hi1;
-                    slab(nd.lo0, nd.hi0, o, ix, iy, iz, closest, lo0, hi0);
-                    slab(nd.lo1, nd.hi1, o, ix, iy, iz, closest, lo1, hi1);
-                    const bool p0 = !(hi0 <= lo0), p1 = !(hi1 <= lo1);
-                    if (STATS) n_box_hits += (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
-                    if (p0 && p1) {
-                        const bool second_first = lo1 < lo0;
-                        stk_node[sp] = second_first ? nd.child0 : nd.child1;    // sp < tree depth <= kStackDepth (checked by the host)
-                        stk_lo[sp] = second_first ? lo0 : lo1;
-                        sp++;
-                        cur = second_first ? nd.child1 : nd.child0;
-                    } else if (p0) cur = nd.child0;
-                    else if (p1) cur = nd.child1;
-                    else pop = true;
-                } else {
+                {
                     // four children: sort the ones the ray enters by entry distance, go to the nearest, push the rest
                     double e[4];
                     int n_in = 0;
@@ -379,7 +374,14 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
                 const bool inside = tri_test(tr, o, d, 0.001, closest, t, u, v);
                 if (STATS) { n_tri++; if (inside) n_tri_hits++; }
                 if (inside) {
-                    if (SHADOW) { h.tri = tr.pad; done = true; leaf_left = 0; }
+                    if (SHADOW) {
+                        // Away from both ends of the interval the boxes above an accepted triangle contain the hit
+                        // point with the ray well inside the interval, so they pass; only a hit at an end of the
+                        // interval (the far end point's own surface, t = max_t up to rounding) needs the check.
+                        const double margin = 1e-9 * closest + 1e-12;
+                        const bool at_an_end = (closest - t <= margin) || (t - 0.001 <= margin);
+                        if (!at_an_end || reference_reaches(sc, sc.sleaf[tr.pad], o, ix, iy, iz, closest)) { h.tri = tr.pad; done = true; leaf_left = 0; }
+                    }
                     // equal t: the reference keeps the triangle it visits later = larger position in
                     // its leaf order (tr.pad)
                     else if (t < closest || best_pos < 0 || tr.pad > best_pos) {
@@ -393,11 +395,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
             done = true;
             while (sp > 0) {
                 sp--;
-                if constexpr (SHADOW) {
-                    const double e_lo = stk_lo[sp];
-                    const int32_t e_node = stk_node[sp];
-                    if (!(closest <= e_lo)) { cur = e_node; done = false; break; }    // aabb.h:61 with the current bound
-                } else {
+                {
                     const double e = stk_quad[sp];
                     // strict: a triangle at exactly the running distance may still win the tie
                     if (!(closest < (double)quad_entry_near(e))) { cur = quad_entry_child(e); done = false; break; }
@@ -418,7 +416,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
                 }
             } else {
                 const uint64_t ns = wb.ns;
-                wb.hit_tri[slot] = (h.tri >= 0) ? stris[h.tri].pad : -1;      // leaf position -> triangle id
+                wb.hit_tri[slot] = (h.tri >= 0) ? sc.stris[h.tri].pad : -1;      // leaf position -> triangle id
                 if (h.tri >= 0) { wb.hit[slot] = h.t; wb.hit[ns + slot] = h.u; wb.hit[2 * ns + slot] = h.v; }
             }
             has = false;
@@ -426,7 +424,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const GpuTri* stris, const WfBuffer
     }
     if (STATS) {
         flush_wave_counter(&stats[SHADOW ? 6 : 0], n_rays);
-        flush_wave_counter(&stats[1], (SHADOW ? 2ull : 4ull) * n_records);
+        flush_wave_counter(&stats[1], 4ull * n_records);
         flush_wave_counter(&stats[2], n_box_hits);
         flush_wave_counter(&stats[3], 2ull * n_records);   // in units of 64 bytes fetched (both record types are 128 bytes)
         flush_wave_counter(&stats[4], n_tri);
@@ -457,8 +455,6 @@ BDPT_DEV void stage_tree(const NodeT* nodes, uint32_t n_nodes, const GpuTri* tri
     __syncthreads();
 }
 
-// SHADOW walks the reference's own tree (GpuWideNode): whether a visibility query is blocked depends on
-// that tree's boxes.  Closest-hit queries walk the surface-area-heuristic hierarchy (GpuQuadNode).
 template <bool SHADOW, bool STATS, bool LDS_SCENE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
                                                     const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
@@ -466,33 +462,19 @@ __global__ __launch_bounds__(BLOCK) void k_traverse(SceneDev sc, WfBuffers wb, c
                                                     uint32_t top_nodes, int leaf_threshold) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
-    if (SHADOW) {
-        if (LDS_SCENE) {
-            GpuWideNode* l_nodes = reinterpret_cast<GpuWideNode*>(smem);
-            GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_wnodes);
-            stage_tree(sc.wnodes, sc.n_wnodes, sc.stris, sc.n_tris, l_nodes, l_tris);
-            TreeMem<GpuWideNode> mem{l_nodes, l_tris};
-            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound);
-        } else {
-            GpuWideNode* l_nodes = reinterpret_cast<GpuWideNode*>(smem);
-            const uint32_t n_top = sc.n_wnodes < top_nodes ? sc.n_wnodes : top_nodes;
-            stage_tree(sc.wnodes, n_top, sc.stris, 0u, l_nodes, (GpuTri*)nullptr);
-            TopLdsMem<GpuWideNode> mem{l_nodes, sc.wnodes, sc.stris, (int32_t)n_top};
-            traverse_queue<true, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound);
-        }
-    } else {
+    {
         if (LDS_SCENE) {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
             stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
             TreeMem<GpuQuadNode> mem{l_nodes, l_tris};
-            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound);
+            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound);
         } else {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
             stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
             TopLdsMem<GpuQuadNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
-            traverse_queue<false, STATS>(mem, sc.stris, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound);
+            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound);
         }
     }
 }

@@ -782,6 +782,31 @@ void oracle_trace_closest(const oracle_scene* s, const double* rays, uint64_t n,
     }
 }
 
+// The same query answered without any hierarchy: is ANY triangle accepted in the interval?  Differs from
+// oracle_visible exactly where the reference's box tests keep it from testing a triangle that would accept.
+void oracle_visible_all_triangles(const oracle_scene* s, const double* pairs, uint64_t n, double* out) {
+    Stats st;
+    memset(&st, 0, sizeof st);
+    for (uint64_t i = 0; i < n; i++) {
+        const double* p = pairs + 6 * i;
+        V3 a = mk(p[0], p[1], p[2]), b = mk(p[3], p[4], p[5]);
+        V3 dir = sub(b, a);
+        double dist = len(dir);
+        out[i] = 0.0;
+        if (dist <= 0) continue;
+        V3 dir_unit = divs(dir, dist);
+        Ray shadow;
+        shadow.o = add(a, scl(0.001, dir_unit));
+        shadow.d = dir_unit;
+        double max_t = dist - 0.001;
+        if (max_t <= 0) continue;
+        bool blocked = false;
+        Hit tmp;
+        for (size_t t = 0; t < s->tris.size() && !blocked; t++) blocked = tri_hit(*s, (int32_t)t, shadow, 0.001, max_t, tmp, st);
+        out[i] = blocked ? 0.0 : 1.0;
+    }
+}
+
 void oracle_visible(const oracle_scene* s, const double* pairs, uint64_t n, double* out) {
     Stats st;
     memset(&st, 0, sizeof st);

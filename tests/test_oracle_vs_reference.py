@@ -158,3 +158,30 @@ def test_unidirectional_estimator(name, scenes, oracle):
     assert_bit_equal(fb, g["framebuffer"], "framebuffer sums")
     assert np.array_equal(stats[:6], g["render_stats"][:6]), "BvhStats"
     assert stats[7] == g["render_stats"][7], "RNG draw total"
+
+
+def test_visibility_depends_on_the_reference_boxes(scenes, oracle):
+    """camera::visible asks bvh_node::hit whether ANY triangle is accepted in [0.001, |b - a| - 0.001]; the far end point
+    lies on a surface at exactly the end of that interval, and a bvh_node box whose face coincides with that surface is
+    entered at the same t - when rounding makes aabb::hit fail there, the reference never tests the triangle.  So the
+    answer is NOT "some triangle accepts": this test keeps that fact visible (the product's visibility walk re-checks
+    the reference's boxes for exactly these hits)."""
+    import ctypes as C
+    flat = scenes.cornell_box(64, 16, 10)
+    osc = oracle.scene(flat)
+    rng = np.random.default_rng(1)
+    n = 60000
+    rays = np.concatenate([rng.uniform(50, 500, size=(n, 3)), rng.normal(size=(n, 3)), np.full((n, 1), 0.001), np.full((n, 1), np.inf)], axis=1)
+    hits = osc.trace_closest(rays)[0]
+    pts = hits[hits[:, 0] >= 0][:, 5:8]
+    m = len(pts) // 2
+    pairs = np.ascontiguousarray(np.concatenate([pts[:m], pts[m:2 * m]], axis=1))
+    with_boxes = osc.visible(pairs)
+    d = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    oracle.lib.oracle_visible_all_triangles.argtypes = [C.c_void_p, d, C.c_uint64, d]
+    any_triangle = np.zeros(len(pairs))
+    oracle.lib.oracle_visible_all_triangles(osc.h, pairs, len(pairs), any_triangle)
+    differ = with_boxes != any_triangle.astype(np.uint8)
+    assert differ.any(), "expected pairs whose end-point triangle accepts but is culled by a reference box"
+    # always in the same direction: the hierarchy can only hide an accepting triangle
+    assert (with_boxes[differ] == 1).all() and differ.mean() < 0.02
