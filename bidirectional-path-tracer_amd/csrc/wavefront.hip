@@ -689,26 +689,33 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
             s_base = run ? atomicAdd(shadow_count, run) : 0u;
         }
         __syncthreads();
-        uint64_t e = (uint64_t)s_base + s_wave_off[wave] + incl - total;
-        // pass 2: the rays
+        // pass 2: the rays.  A wave's entries are ordered by (j, light vertex, lane), not by lane: the lanes that
+        // write in one iteration then write neighbouring entries.
+        uint64_t wave_next = (uint64_t)s_base + s_wave_off[wave];
 #pragma unroll 1
         for (int j = 0; j < kStagePerThread; j++) {
-            if (mine[j] == 0) continue;
             const uint32_t slot = slots[j];
-            const Vertex cv = slot_store(wb, slot).get(a);
-            for (uint32_t bi = 0; bi < mine[j]; bi++, e++) {
-                const Vertex lv = slot_store(wb, slot).get(depth + (int)bi);
-                PairGeom g;
-                V3 f_cam, f_light;
-                const bool emit = pair_geometry(cv, lv, g) && pair_factors(sc, cv, lv, f_cam, f_light);
-                if (emit) {
-                    wb.shadow[e] = g.origin.x; wb.shadow[cap + e] = g.origin.y; wb.shadow[2 * cap + e] = g.origin.z;
-                    wb.shadow[3 * cap + e] = g.dir_unit.x; wb.shadow[4 * cap + e] = g.dir_unit.y; wb.shadow[5 * cap + e] = g.dir_unit.z;
-                    wb.shadow[6 * cap + e] = g.max_t;
-                    wb.shadow[7 * cap + e] = __longlong_as_double((long long)(((unsigned long long)slot << 16) | bi));
-                } else {
-                    wb.shadow[6 * cap + e] = -1.0;
+            Vertex cv;
+            if (mine[j]) cv = slot_store(wb, slot).get(a);
+            for (uint32_t bi = 0;; bi++) {
+                const unsigned long long writers = __ballot(bi < mine[j]);
+                if (writers == 0) break;
+                if (bi < mine[j]) {
+                    const uint64_t e = wave_next + rank_in_mask(writers);
+                    const Vertex lv = slot_store(wb, slot).get(depth + (int)bi);
+                    PairGeom g;
+                    V3 f_cam, f_light;
+                    const bool emit = pair_geometry(cv, lv, g) && pair_factors(sc, cv, lv, f_cam, f_light);
+                    if (emit) {
+                        wb.shadow[e] = g.origin.x; wb.shadow[cap + e] = g.origin.y; wb.shadow[2 * cap + e] = g.origin.z;
+                        wb.shadow[3 * cap + e] = g.dir_unit.x; wb.shadow[4 * cap + e] = g.dir_unit.y; wb.shadow[5 * cap + e] = g.dir_unit.z;
+                        wb.shadow[6 * cap + e] = g.max_t;
+                        wb.shadow[7 * cap + e] = __longlong_as_double((long long)(((unsigned long long)slot << 16) | bi));
+                    } else {
+                        wb.shadow[6 * cap + e] = -1.0;
+                    }
                 }
+                wave_next += (uint64_t)__builtin_popcountll(writers);
             }
         }
         __syncthreads();
