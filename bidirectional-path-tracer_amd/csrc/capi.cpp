@@ -241,8 +241,6 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     cfg.lds_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuQuadNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
     cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
     if (!cfg.lds_scene) cfg.lds_bytes = 0;
-    cfg.trav_block = env_int("BDPT_WF_TRAV_BLOCK", 256);
-    if (cfg.trav_block != 256 && cfg.trav_block != 512 && cfg.trav_block != 1024) cfg.trav_block = 256;
     {
         int kb = env_int("BDPT_WF_LDS_KB", 32);
         if (kb < 1) kb = 1;
@@ -251,7 +249,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     }
     int per_cu = 1;
     HIP_TRY(wf_prepare_traverse(cfg, &per_cu));
-    if (!cfg.lds_scene && per_cu * cfg.trav_block > 768) per_cu = 768 / cfg.trav_block > 0 ? 768 / cfg.trav_block : 1;   // measured: more resident waves only thrash L1 on large scenes
+    if (!cfg.lds_scene && per_cu > 3) per_cu = 3;   // measured: more resident waves only thrash L1 on large scenes
     per_cu = env_int("BDPT_WF_BLOCKS_PER_CU", per_cu);
     cfg.persistent_blocks = ctx->cu_count * per_cu;
     cfg.refill_threshold = env_int("BDPT_WF_REFILL", 16);

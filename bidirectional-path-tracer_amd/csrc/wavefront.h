@@ -57,7 +57,6 @@ struct WfLaunchCfg {
     int refill_threshold;     // a wave fetches new rays when at least this many of its lanes are idle
     int leaf_threshold;       // lanes of a wave that must stand at a leaf before the wave turns to triangle tests
     uint32_t chunk;           // ray indices a wave takes from the global cursor at a time
-    int trav_block;           // threads per traversal workgroup when the scene does not fit LDS (256, 512 or 1024)
     uint32_t top_nodes;       // 128-byte records of the top tree levels each such workgroup keeps in LDS
 };
 

@@ -163,7 +163,7 @@ struct TopLdsMem {
     BDPT_DEV GpuTri stri(uint32_t i) const { return st[i]; }
 };
 
-// Box tests of the closest-hit hierarchy only have to be conservative, so they run in packed FP32 with
+// Box tests of the traversal hierarchy only have to be conservative, so they run in packed FP32 with
 // the rounding error carried explicitly.  Per axis the ray keeps inv = fl(1/d) and the pair
 // (c_min, c_max) = fl(-o/d) -/+ slack; the distances to the two planes of a box are then ONE packed fma,
 // (box_min, box_max) * inv + (c_min, c_max) for 1/d > 0 (pair swapped otherwise), giving a lower bound of
@@ -455,8 +455,8 @@ BDPT_DEV void stage_tree(const NodeT* nodes, uint32_t n_nodes, const GpuTri* tri
     __syncthreads();
 }
 
-template <bool SHADOW, bool STATS, bool LDS_SCENE, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
+template <bool SHADOW, bool STATS, bool LDS_SCENE>
+__global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
                                                     const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                     unsigned long long* stats, int refill_threshold, uint32_t chunk,
                                                     uint32_t top_nodes, int leaf_threshold) {
@@ -781,45 +781,40 @@ __global__ __launch_bounds__(kBlock) void k_resolve(GpuCamera cam, WfBuffers wb,
 }  // namespace
 
 // ------------------------------------------------------------------------------ launchers
-// Traversal launch shape: scenes that fit LDS whole run 256-thread workgroups; larger scenes run
-// `trav_block`-thread workgroups that share an LDS copy of the first `top_nodes` 64-byte records.
-template <bool SHADOW, bool STATS, bool LDS_SCENE, int BLOCK>
+// Sets the LDS limit of one traversal kernel (more than 64 KiB of dynamic LDS has to be requested) and reports
+// how many of its workgroups fit a CU.
+template <bool SHADOW, bool STATS, bool LDS_SCENE>
 static hipError_t prepare_traverse(size_t shm, int* blocks_per_cu) {
-    auto fn = k_traverse<SHADOW, STATS, LDS_SCENE, BLOCK>;
+    auto fn = k_traverse<SHADOW, STATS, LDS_SCENE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     if (blocks_per_cu) {
         int n = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, BLOCK, shm);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kBlock, shm);
         *blocks_per_cu = n < 1 ? 1 : n;
     }
     return e;
 }
 
-template <int BLOCK>
-static hipError_t prepare_traverse_block(size_t shm, int* blocks_per_cu) {
-    hipError_t e = prepare_traverse<false, false, false, BLOCK>(shm, blocks_per_cu);
-    if (e == hipSuccess) e = prepare_traverse<false, true, false, BLOCK>(shm, nullptr);
-    if (e == hipSuccess) e = prepare_traverse<true, false, false, BLOCK>(shm, nullptr);
-    if (e == hipSuccess) e = prepare_traverse<true, true, false, BLOCK>(shm, nullptr);
-    return e;
+static size_t traverse_lds_bytes(const WfLaunchCfg& cfg) {
+    return cfg.lds_scene ? cfg.lds_bytes : (size_t)cfg.top_nodes * sizeof(GpuQuadNode);
 }
 
 hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu) {
+    const size_t shm = traverse_lds_bytes(cfg);
+    hipError_t e;
     if (cfg.lds_scene) {
-        hipError_t e = prepare_traverse<false, false, true, 256>(cfg.lds_bytes, blocks_per_cu);
-        if (e == hipSuccess) e = prepare_traverse<false, true, true, 256>(cfg.lds_bytes, nullptr);
-        if (e == hipSuccess) e = prepare_traverse<true, false, true, 256>(cfg.lds_bytes, nullptr);
-        if (e == hipSuccess) e = prepare_traverse<true, true, true, 256>(cfg.lds_bytes, nullptr);
-        return e;
+        e = prepare_traverse<false, false, true>(shm, blocks_per_cu);
+        if (e == hipSuccess) e = prepare_traverse<false, true, true>(shm, nullptr);
+        if (e == hipSuccess) e = prepare_traverse<true, false, true>(shm, nullptr);
+        if (e == hipSuccess) e = prepare_traverse<true, true, true>(shm, nullptr);
+    } else {
+        e = prepare_traverse<false, false, false>(shm, blocks_per_cu);
+        if (e == hipSuccess) e = prepare_traverse<false, true, false>(shm, nullptr);
+        if (e == hipSuccess) e = prepare_traverse<true, false, false>(shm, nullptr);
+        if (e == hipSuccess) e = prepare_traverse<true, true, false>(shm, nullptr);
     }
-    const size_t shm = (size_t)cfg.top_nodes * 128;
-    switch (cfg.trav_block) {
-        case 256: return prepare_traverse_block<256>(shm, blocks_per_cu);
-        case 512: return prepare_traverse_block<512>(shm, blocks_per_cu);
-        case 1024: return prepare_traverse_block<1024>(shm, blocks_per_cu);
-        default: return hipErrorInvalidValue;
-    }
+    return e;
 }
 
 hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const WfLaunchCfg& cfg,
@@ -828,32 +823,27 @@ hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers&
     return hipGetLastError();
 }
 
-template <bool SHADOW, bool STATS, bool LDS_SCENE, int BLOCK>
+template <bool SHADOW, bool STATS, bool LDS_SCENE>
 static void launch_traverse_as(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                                uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
                                hipStream_t st) {
-    const size_t shm = LDS_SCENE ? cfg.lds_bytes : (size_t)cfg.top_nodes * 128;
-    hipLaunchKernelGGL((k_traverse<SHADOW, STATS, LDS_SCENE, BLOCK>), dim3(cfg.persistent_blocks), dim3(BLOCK), shm, st, sc, wb,
-                       queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.top_nodes, cfg.leaf_threshold);
-}
-
-template <bool SHADOW, bool STATS>
-static hipError_t launch_traverse_stats(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
-                                        uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
-                                        hipStream_t st) {
-    if (cfg.lds_scene) launch_traverse_as<SHADOW, STATS, true, 256>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
-    else if (cfg.trav_block == 256) launch_traverse_as<SHADOW, STATS, false, 256>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
-    else if (cfg.trav_block == 512) launch_traverse_as<SHADOW, STATS, false, 512>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
-    else launch_traverse_as<SHADOW, STATS, false, 1024>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
-    return hipGetLastError();
+    hipLaunchKernelGGL((k_traverse<SHADOW, STATS, LDS_SCENE>), dim3(cfg.persistent_blocks), dim3(kBlock), traverse_lds_bytes(cfg), st,
+                       sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.top_nodes,
+                       cfg.leaf_threshold);
 }
 
 template <bool SHADOW>
 static hipError_t launch_traverse(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                                   uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
                                   hipStream_t st) {
-    return stats ? launch_traverse_stats<SHADOW, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st)
-                 : launch_traverse_stats<SHADOW, false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+    if (stats) {
+        if (cfg.lds_scene) launch_traverse_as<SHADOW, true, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+        else launch_traverse_as<SHADOW, true, false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+    } else {
+        if (cfg.lds_scene) launch_traverse_as<SHADOW, false, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+        else launch_traverse_as<SHADOW, false, false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+    }
+    return hipGetLastError();
 }
 
 hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
