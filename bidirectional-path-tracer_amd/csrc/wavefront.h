@@ -35,9 +35,8 @@ struct WfBuffers {
 // entries of the closest-hit walk's stack (up to three pushes per level of the four-wide tree)
 constexpr int kQuadStackEntries = 64;
 
-constexpr uint32_t kCntEyeHit = 1u << 24, kCntLightHit = 1u << 25, kCntLightValid = 1u << 26;
 // the eye subpath stored at least one vertex that can form a non-zero connection (non-delta, not on an emitter)
-constexpr uint32_t kCntEyeConnectable = 1u << 27;
+constexpr uint32_t kCntEyeConnectable = 1u << 24;
 
 struct WfBatch {
     uint64_t seed;

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             Rng rng = slot_rng(cam, b, slot, wb.ctr[slot]);
             Bounce bo;
             shade_bounce<EYE>(sc, o, d, h, T, rng, bo);
-            uint32_t cnt = wb.counts[slot] | (EYE ? kCntEyeHit : kCntLightHit);
+            uint32_t cnt = wb.counts[slot];
             if (bo.keep) {
                 const uint32_t ne = cnt & 0xFFFu, nl = (cnt >> 12) & 0xFFFu;
                 slot_store(wb, slot).put(EYE ? (int)ne : depth + (int)nl, bo.vx);
@@ -567,23 +567,22 @@ __global__ __launch_bounds__(kStageBlock) void k_gen_light(SceneDev sc, GpuCamer
             slots[j] = slot;
             int pi, pj, ps;
             if (slot >= n || !slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
+            // A light subpath only acts through its connections (camera.h:316-320), and a pair contributes zero
+            // when the eye vertex is delta (camera.h:441) or on an emitter (zero BSDF, material.h:35-37): without
+            // a connectable eye vertex nothing of the light subpath is sampled, traced or stored.  Its random
+            // draws are the last ones of the sample's stream, so nothing else shifts.  (The reference still adds
+            // the all-zero pair colours in that case; x + 0 changes only a -0, and the radiance so far is never
+            // -0: every term enters it as 0 + term.)
+            const uint32_t cnt = wb.counts[slot];
+            if (!(cnt & kCntEyeConnectable)) continue;
             Rng rng = slot_rng(cam, b, slot, wb.ctr[slot]);
             Emitter em;
             sample_emitter(sc, depth, rng, em);
             wb.ctr[slot] = rng.counter;
             if (!em.valid) continue;
-            const uint32_t cnt = wb.counts[slot];
-            // A light subpath only matters through its connections (camera.h:316-320), and a pair contributes
-            // zero when the eye vertex is delta (camera.h:441) or on an emitter (zero BSDF, material.h:35-37):
-            // without a connectable eye vertex the subpath is not traced and nothing of it is stored.  Its
-            // random draws come after everything else the sample draws, so skipping them changes nothing.
-            if (!(cnt & kCntEyeConnectable)) {
-                wb.counts[slot] = cnt | kCntLightValid | kCntLightHit;
-                continue;
-            }
             slot_store(wb, slot).put(depth, em.ev);
             if (STATS) n_stored++;
-            wb.counts[slot] = cnt | kCntLightValid | kCntLightHit | (1u << 12);
+            wb.counts[slot] = cnt | (1u << 12);
             if (em.has_ray && depth - 1 > 0) {
                 cont[j] = true;
                 wb.ray[slot] = em.o.x; wb.ray[ns + slot] = em.o.y; wb.ray[2 * ns + slot] = em.o.z;
@@ -597,13 +596,13 @@ __global__ __launch_bounds__(kStageBlock) void k_gen_light(SceneDev sc, GpuCamer
 }
 
 // ------------------------------------------------------------------ connections
-// samples that have a light path and at least one stored vertex on both sides
+// samples that have at least one stored vertex on both sides (a light vertex exists only where the emitter
+// sample was valid and the eye subpath is connectable, see k_gen_light)
 template <bool STATS>
 __global__ __launch_bounds__(kStageBlock) void k_conn_prepare(GpuCamera cam, WfBuffers wb, WfBatch b, uint32_t* conn_count,
                                                          unsigned long long* stats) {
     const uint32_t spp = (uint32_t)(cam.sqrt_spp * cam.sqrt_spp);
     const uint32_t n = (uint32_t)b.pixels_stride * spp;
-    const uint64_t ns = wb.ns;
     __shared__ uint32_t s_wave[kStageWaves];
     __shared__ uint32_t s_base;
     unsigned long long draws = 0, samples = 0;
@@ -619,16 +618,7 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_prepare(GpuCamera cam, WfB
             if (slot >= n || !slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
             const uint32_t cnt = wb.counts[slot];
             if (STATS) { draws += wb.ctr[slot]; samples++; }
-            if (cnt & kCntLightValid) {
-                // camera.h:316-320 adds a colour (possibly zero) for every vertex pair: x + (+0) only
-                // changes a -0 accumulator, which this one add normalises
-                if ((cnt & kCntEyeHit) && (cnt & kCntLightHit)) {
-                    wb.result[slot] = wb.result[slot] + 0.0;
-                    wb.result[ns + slot] = wb.result[ns + slot] + 0.0;
-                    wb.result[2 * ns + slot] = wb.result[2 * ns + slot] + 0.0;
-                }
-                want[j] = (cnt & 0xFFFu) > 0 && ((cnt >> 12) & 0xFFFu) > 0;
-            }
+            want[j] = (cnt & 0xFFFu) > 0 && ((cnt >> 12) & 0xFFFu) > 0;
         }
         tile_append(want, slots, wb.conn_queue, conn_count, s_wave, &s_base);
     }
