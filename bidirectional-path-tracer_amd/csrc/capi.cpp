@@ -242,14 +242,17 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
     if (!cfg.lds_scene) cfg.lds_bytes = 0;
     {
-        int kb = env_int("BDPT_WF_LDS_KB", 32);
+        int kb = env_int("BDPT_WF_LDS_KB", 16);
         if (kb < 1) kb = 1;
         if (kb > 128) kb = 128;
         cfg.top_nodes = (uint32_t)kb * 1024u / 128u;
     }
+    cfg.lds_stack = env_int("BDPT_WF_LDS_STACK", 8);
+    if (cfg.lds_stack < 0) cfg.lds_stack = 0;
+    if (cfg.lds_stack > kQuadStackEntries) cfg.lds_stack = kQuadStackEntries;
     int per_cu = 1;
     HIP_TRY(wf_prepare_traverse(cfg, &per_cu));
-    if (!cfg.lds_scene && per_cu > 3) per_cu = 3;   // measured: more resident waves only thrash L1 on large scenes
+    if (!cfg.lds_scene && per_cu > 4) per_cu = 4;   // measured: more resident waves only thrash L1 on large scenes
     per_cu = env_int("BDPT_WF_BLOCKS_PER_CU", per_cu);
     cfg.persistent_blocks = ctx->cu_count * per_cu;
     cfg.refill_threshold = env_int("BDPT_WF_REFILL", 16);

@@ -57,6 +57,7 @@ struct WfLaunchCfg {
     int leaf_threshold;       // lanes of a wave that must stand at a leaf before the wave turns to triangle tests
     uint32_t chunk;           // ray indices a wave takes from the global cursor at a time
     uint32_t top_nodes;       // 128-byte records of the top tree levels each such workgroup keeps in LDS
+    int lds_stack;            // traversal stack entries per lane kept in LDS (the rest of the stack is scratch)
 };
 
 // counts of the work done, accumulated by the kernels when `stats` is non-null (bdpt_stats order)

@@ -264,13 +264,22 @@ BDPT_DEV bool reference_reaches(const SceneDev& sc, uint32_t node, V3 o, double 
 template <bool SHADOW, bool STATS, class Mem>
 BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, uint32_t count,
                              uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk,
-                             const int kLeafThreshold, const double coord_bound) {
+                             const int kLeafThreshold, const double coord_bound, double* lds_stack, const int kLdsStack) {
     bool has = false;
     uint32_t slot = 0;
     int32_t cur = kPop;                 // interior record to visit next (when leaf_left == 0)
     uint32_t leaf_next = 0, leaf_left = 0;   // triangles of the current leaf still to test
     int sp = 0;
-    double stk_quad[kQuadStackDepth];   // one 64-bit word per entry, see quad_entry()
+    // One 64-bit word per entry, see quad_entry().  The first kLdsStack entries (the ones pushed and popped most)
+    // live in LDS, column threadIdx.x of a [kLdsStack][kBlock] array: a pop is then an LDS read instead of a
+    // scratch read that competes with the node records for the vector L1.  Deeper entries go to scratch.
+    double stk_quad[kQuadStackDepth];
+    double* const lstk = lds_stack + threadIdx.x;
+    auto push = [&](double e) {
+        if (sp < kLdsStack) lstk[sp * kBlock] = e;
+        else stk_quad[sp - kLdsStack] = e;
+        sp++;
+    };
     unsigned long long tag = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     double ix = 0, iy = 0, iz = 0, closest = 0;
@@ -357,9 +366,9 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                     if (STATS) n_box_hits += (uint32_t)n_in;
                     sort2(e[0], e[1]); sort2(e[2], e[3]); sort2(e[0], e[2]); sort2(e[1], e[3]); sort2(e[1], e[2]);
                     // sp + 3 <= kQuadStackDepth: the host checks the worst case of the tree
-                    if (n_in > 3) stk_quad[sp++] = e[3];
-                    if (n_in > 2) stk_quad[sp++] = e[2];
-                    if (n_in > 1) stk_quad[sp++] = e[1];
+                    if (n_in > 3) push(e[3]);
+                    if (n_in > 2) push(e[2]);
+                    if (n_in > 1) push(e[1]);
                     if (n_in > 0) cur = quad_entry_child(e[0]);
                     else pop = true;
                 }
@@ -396,7 +405,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
             while (sp > 0) {
                 sp--;
                 {
-                    const double e = stk_quad[sp];
+                    const double e = (sp < kLdsStack) ? lstk[sp * kBlock] : stk_quad[sp - kLdsStack];
                     // strict: a triangle at exactly the running distance may still win the tie
                     if (!(closest < (double)quad_entry_near(e))) { cur = quad_entry_child(e); done = false; break; }
                 }
@@ -459,22 +468,23 @@ template <bool SHADOW, bool STATS, bool LDS_SCENE>
 __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
                                                     const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                     unsigned long long* stats, int refill_threshold, uint32_t chunk,
-                                                    uint32_t top_nodes, int leaf_threshold) {
+                                                    uint32_t top_nodes, int leaf_threshold, uint32_t scene_lds_bytes, int lds_stack) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
+    double* const l_stack = reinterpret_cast<double*>(smem + scene_lds_bytes);     // [lds_stack][kBlock]
     {
         if (LDS_SCENE) {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
             stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
             TreeMem<GpuQuadNode> mem{l_nodes, l_tris};
-            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound);
+            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound, l_stack, lds_stack);
         } else {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
             stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
             TopLdsMem<GpuQuadNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
-            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound);
+            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound, l_stack, lds_stack);
         }
     }
 }
@@ -786,8 +796,11 @@ static hipError_t prepare_traverse(size_t shm, int* blocks_per_cu) {
     return e;
 }
 
-static size_t traverse_lds_bytes(const WfLaunchCfg& cfg) {
+static size_t scene_lds_bytes(const WfLaunchCfg& cfg) {
     return cfg.lds_scene ? cfg.lds_bytes : (size_t)cfg.top_nodes * sizeof(GpuQuadNode);
+}
+static size_t traverse_lds_bytes(const WfLaunchCfg& cfg) {
+    return scene_lds_bytes(cfg) + (size_t)cfg.lds_stack * kBlock * sizeof(double);
 }
 
 hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu) {
@@ -819,7 +832,7 @@ static void launch_traverse_as(const SceneDev& sc, const WfBuffers& wb, const ui
                                hipStream_t st) {
     hipLaunchKernelGGL((k_traverse<SHADOW, STATS, LDS_SCENE>), dim3(cfg.persistent_blocks), dim3(kBlock), traverse_lds_bytes(cfg), st,
                        sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.top_nodes,
-                       cfg.leaf_threshold);
+                       cfg.leaf_threshold, (uint32_t)scene_lds_bytes(cfg), cfg.lds_stack);
 }
 
 template <bool SHADOW>
