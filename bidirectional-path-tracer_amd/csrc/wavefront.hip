@@ -240,7 +240,11 @@ BDPT_DEV double quad_entry(bool in, float near, int32_t child) {
 BDPT_DEV int32_t quad_entry_child(double e) { return (int32_t)(uint32_t)(unsigned long long)__double_as_longlong(e); }
 BDPT_DEV float quad_entry_near(double e) { return __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(e) >> 32)); }
 BDPT_DEV void sort2(double& a, double& b) {
-    const double lo = __builtin_fmin(a, b), hi = __builtin_fmax(a, b);
+    // the instructions themselves: fmin()/fmax() would first quiet possible signalling NaNs of both operands
+    // (one more instruction each), and these words are never NaNs
+    double lo, hi;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
     a = lo; b = hi;
 }
 
@@ -366,9 +370,18 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                     if (STATS) n_box_hits += (uint32_t)n_in;
                     sort2(e[0], e[1]); sort2(e[2], e[3]); sort2(e[0], e[2]); sort2(e[1], e[3]); sort2(e[1], e[2]);
                     // sp + 3 <= kQuadStackDepth: the host checks the worst case of the tree
-                    if (n_in > 3) push(e[3]);
-                    if (n_in > 2) push(e[2]);
-                    if (n_in > 1) push(e[1]);
+                    if (sp + 3 <= kLdsStack) {
+                        // all in LDS: three stores without a branch, e[k] to row sp + n_in - 1 - k (the nearest
+                        // on top); a child the ray misses goes to the spare row kLdsStack
+                        lstk[(n_in > 3 ? sp : kLdsStack) * kBlock] = e[3];
+                        lstk[(n_in > 2 ? sp + n_in - 3 : kLdsStack) * kBlock] = e[2];
+                        lstk[(n_in > 1 ? sp + n_in - 2 : kLdsStack) * kBlock] = e[1];
+                        sp += n_in > 1 ? n_in - 1 : 0;
+                    } else {
+                        if (n_in > 3) push(e[3]);
+                        if (n_in > 2) push(e[2]);
+                        if (n_in > 1) push(e[1]);
+                    }
                     if (n_in > 0) cur = quad_entry_child(e[0]);
                     else pop = true;
                 }
@@ -471,7 +484,7 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
                                                     uint32_t top_nodes, int leaf_threshold, uint32_t scene_lds_bytes, int lds_stack) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
-    double* const l_stack = reinterpret_cast<double*>(smem + scene_lds_bytes);     // [lds_stack][kBlock]
+    double* const l_stack = reinterpret_cast<double*>(smem + scene_lds_bytes);     // [lds_stack + 1][kBlock]
     {
         if (LDS_SCENE) {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
@@ -527,28 +540,36 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
             HitLite h;
             h.tri = tri; h.t = wb.hit[slot]; h.u = wb.hit[ns + slot]; h.v = wb.hit[2 * ns + slot];
-            Rng rng = slot_rng(cam, b, slot, wb.ctr[slot]);
+            const uint32_t ctr0 = wb.ctr[slot];
+            Rng rng = slot_rng(cam, b, slot, ctr0);
             Bounce bo;
             shade_bounce<EYE>(sc, o, d, h, T, rng, bo);
-            uint32_t cnt = wb.counts[slot];
+            // state that a bounce leaves as it was is not written again (a specular bounce keeps no vertex, a
+            // dielectric one leaves the throughput alone: x * 1.0 is x)
             if (bo.keep) {
+                uint32_t cnt = wb.counts[slot];
                 const uint32_t ne = cnt & 0xFFFu, nl = (cnt >> 12) & 0xFFFu;
                 slot_store(wb, slot).put(EYE ? (int)ne : depth + (int)nl, bo.vx);
                 cnt += EYE ? 1u : (1u << 12);
                 if (EYE && !(bo.vx.info & kVtxIsLight)) cnt |= kCntEyeConnectable;
                 if (STATS) n_stored++;
+                wb.counts[slot] = cnt;
             }
-            wb.counts[slot] = cnt;
             if (EYE && bo.emitted) {   // result = background_contrib (0) + throughput * emission
                 V3 e = add(mk(0, 0, 0), bo.emitted_term);
                 wb.result[slot] = e.x; wb.result[ns + slot] = e.y; wb.result[2 * ns + slot] = e.z;
             }
-            wb.ctr[slot] = rng.counter;
+            if (rng.counter != ctr0) wb.ctr[slot] = rng.counter;
             if (bo.cont && !last_bounce) {
                 cont[j] = true;
                 wb.ray[slot] = bo.o.x; wb.ray[ns + slot] = bo.o.y; wb.ray[2 * ns + slot] = bo.o.z;
                 wb.ray[3 * ns + slot] = bo.d.x; wb.ray[4 * ns + slot] = bo.d.y; wb.ray[5 * ns + slot] = bo.d.z;
-                wb.thr[slot] = bo.T.x; wb.thr[ns + slot] = bo.T.y; wb.thr[2 * ns + slot] = bo.T.z;
+                const bool same_bits = __double_as_longlong(bo.T.x) == __double_as_longlong(T.x) &&
+                                       __double_as_longlong(bo.T.y) == __double_as_longlong(T.y) &&
+                                       __double_as_longlong(bo.T.z) == __double_as_longlong(T.z);
+                if (!same_bits) {
+                    wb.thr[slot] = bo.T.x; wb.thr[ns + slot] = bo.T.y; wb.thr[2 * ns + slot] = bo.T.z;
+                }
             }
         }
         tile_append(cont, slots, queue_out, count_out, s_wave, &s_base);
@@ -800,7 +821,7 @@ static size_t scene_lds_bytes(const WfLaunchCfg& cfg) {
     return cfg.lds_scene ? cfg.lds_bytes : (size_t)cfg.top_nodes * sizeof(GpuQuadNode);
 }
 static size_t traverse_lds_bytes(const WfLaunchCfg& cfg) {
-    return scene_lds_bytes(cfg) + (size_t)cfg.lds_stack * kBlock * sizeof(double);
+    return scene_lds_bytes(cfg) + (size_t)(cfg.lds_stack + 1) * kBlock * sizeof(double);      // + the spare row
 }
 
 hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu) {
