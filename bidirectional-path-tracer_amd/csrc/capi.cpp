@@ -257,7 +257,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     cfg.persistent_blocks = ctx->cu_count * per_cu;
     cfg.refill_threshold = env_int("BDPT_WF_REFILL", 16);
     cfg.leaf_threshold = env_int("BDPT_WF_LEAF", 24);
-    cfg.chunk = (uint32_t)env_int("BDPT_WF_CHUNK", 128);
+    cfg.chunk = (uint32_t)env_int("BDPT_WF_CHUNK", 512);   // measured: the cursor is one address, and its atomics cost more than a coarser split
     cfg.stream_blocks = ctx->cu_count * 8;
 
     const GpuCamera gcam = to_gpu_camera(*cam);
