@@ -268,7 +268,8 @@ BDPT_DEV bool reference_reaches(const SceneDev& sc, uint32_t node, V3 o, double 
 template <bool SHADOW, bool STATS, class Mem>
 BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, uint32_t count,
                              uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk,
-                             const int kLeafThreshold, const double coord_bound, double* lds_stack, const int kLdsStack) {
+                             const int kLeafThreshold, const double coord_bound, double* lds_stack, const int kLdsStack,
+                             const uint32_t first_base) {
     bool has = false;
     uint32_t slot = 0;
     int32_t cur = kPop;                 // interior record to visit next (when leaf_left == 0)
@@ -291,8 +292,11 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
     HitLite h;
     h.t = 0; h.u = 0; h.v = 0; h.tri = -1;
     int32_t best_pos = -1;
+    // first_base: the wave's first chunk, taken from the cursor by its workgroup for all its waves at once (all
+    // waves start at the same moment: one atomic per wave on one address would queue up)
     uint32_t pool_next = 0, pool_end = 0;     // wave-uniform
-    bool exhausted = (count == 0);
+    if (first_base < count) { pool_next = first_base; pool_end = (first_base + kChunk < count) ? first_base + kChunk : count; }
+    bool exhausted = (pool_next == pool_end);
     uint32_t n_records = 0, n_box_hits = 0, n_tri = 0, n_tri_hits = 0, n_rays = 0;
 
     for (;;) {
@@ -300,9 +304,11 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
         const int n_idle = __builtin_popcountll(idle);
         if (!exhausted && (n_idle >= kRefillThreshold)) {
             if (pool_next == pool_end) {
-                uint32_t base = 0;
-                if (lane_id() == 0) base = atomicAdd(cursor, kChunk);
-                base = __shfl(base, 0, 64);
+                uint32_t base = count;
+                if (cursor) {
+                    if (lane_id() == 0) base = atomicAdd(cursor, kChunk);
+                    base = __shfl(base, 0, 64);
+                }
                 if (base >= count) { exhausted = true; pool_next = pool_end = 0; }
                 else { pool_next = base; pool_end = (base + kChunk < count) ? base + kChunk : count; }
             }
@@ -459,7 +465,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
 // waves instead of waiting their turn inside a few.
 BDPT_DEV uint32_t fair_chunk(uint32_t count, uint32_t chunk) {
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    uint32_t share = (count / n_waves + 15u) & ~15u;
+    uint32_t share = ((count + n_waves - 1u) / n_waves + 15u) & ~15u;      // n_waves * share >= count
     if (share < 16u) share = 16u;
     return share < chunk ? share : chunk;
 }
@@ -485,19 +491,38 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
     double* const l_stack = reinterpret_cast<double*>(smem + scene_lds_bytes);     // [lds_stack + 1][kBlock]
+    const uint32_t wave_chunk = fair_chunk(count, chunk);
+    // The first chunk of every wave.  A short queue (at most 64 entries per wave) is simply dealt out, wave w owns
+    // chunk w, and the launch touches no counter at all; of a longer one each workgroup takes the first chunks of
+    // all its waves with ONE atomic (all waves start at the same moment: one atomic per wave on one address would
+    // queue up), and the waves come back to the cursor for more.  Dealing out a long queue as well would tie
+    // entries to workgroups that start late because kernels of the other batches hold their place.
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    uint32_t first_base;
+    if ((uint64_t)count <= (uint64_t)gridDim.x * waves_per_block * 64u) {
+        if ((uint64_t)blockIdx.x * waves_per_block * wave_chunk >= count) return;       // the whole workgroup
+        first_base = (blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * wave_chunk;
+        cursor = nullptr;
+    } else {
+        __shared__ uint32_t s_first;
+        if (threadIdx.x == 0) s_first = atomicAdd(cursor, waves_per_block * wave_chunk);
+        __syncthreads();
+        if (s_first >= count) return;          // the whole workgroup: nothing left for it
+        first_base = s_first + (threadIdx.x >> 6) * wave_chunk;
+    }
     {
         if (LDS_SCENE) {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
             stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
             TreeMem<GpuQuadNode> mem{l_nodes, l_tris};
-            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound, l_stack, lds_stack);
+            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, sc.coord_bound, l_stack, lds_stack, first_base);
         } else {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
             stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
             TopLdsMem<GpuQuadNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
-            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, fair_chunk(count, chunk), leaf_threshold, sc.coord_bound, l_stack, lds_stack);
+            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, sc.coord_bound, l_stack, lds_stack, first_base);
         }
     }
 }
