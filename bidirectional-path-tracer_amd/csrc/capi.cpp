@@ -40,7 +40,7 @@ int hip_fail(hipError_t e, const char* what) {
 constexpr int kBlock = 256;
 constexpr int kStatWords = 11;
 constexpr int kWfStreams = 8;                               // most batches in flight (one HIP stream each)
-constexpr size_t kWfWorkspaceBudget = (size_t)48 << 30;     // bytes of wavefront state for all of them
+constexpr size_t kWfWorkspaceBudget = (size_t)176 << 30;     // bytes of wavefront state for all of them
 
 // tuning knobs, overridable from the environment for experiments
 int env_int(const char* name, int fallback) {
@@ -188,16 +188,26 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     // bytes of state per sample slot
     const size_t per_slot = sizeof(double) * (6 + 3 + 3 + 3) + sizeof(uint32_t) * 6 + vslots * 10 * sizeof(double) +
                             vis_words * sizeof(unsigned long long) + shadow_per_slot * 8 * sizeof(double);
-    const size_t budget = (size_t)kWfWorkspaceBudget;           // for all batches in flight, of 288 GB
+    // Wavefront state of all batches in flight.  Large batches mean few, long launches (a frame is tens of thousands
+    // of them), so the state takes most of what the device has free: up to kWfWorkspaceBudget of the 288 GB.
+    size_t budget = (size_t)kWfWorkspaceBudget;
+    {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const size_t avail = (free_b + ctx->wf_blob_bytes) / 10 * 7;
+        if (avail < budget) budget = avail;
+        const int gb = env_int("BDPT_WF_BUDGET_GB", 0);
+        if (gb > 0 && gb <= 224) budget = (size_t)gb << 30;
+    }
     int want_streams = env_int("BDPT_WF_STREAMS", 4);
     want_streams = want_streams < 1 ? 1 : (want_streams > kWfStreams ? kWfStreams : want_streams);
     int64_t ns_target = (int64_t)(budget / want_streams / per_slot);
-    const int64_t ns_cap = (int64_t)1 << env_int("BDPT_WF_BATCH_LOG2", 22);
+    const int64_t ns_cap = (int64_t)1 << env_int("BDPT_WF_BATCH_LOG2", 24);
     if (ns_target > ns_cap) ns_target = ns_cap;
     if (spp > ns_target) return fail(BDPT_ERR_UNSUPPORTED, "samples per pixel exceed the wavefront batch capacity");
     int64_t pixels_per_batch = ns_target / spp;
-    // small renders: still split over the streams so that the tails overlap
-    const int64_t even_share = (n_owned + want_streams - 1) / want_streams;
+    // small renders: still three batches per stream, so that the tails of the batches overlap
+    const int64_t even_share = (n_owned + 3 * want_streams - 1) / (3 * want_streams);
     if (pixels_per_batch > even_share) pixels_per_batch = even_share > 0 ? even_share : 1;
     const uint64_t ns = (uint64_t)(pixels_per_batch * spp);
     const uint64_t shadow_cap = ns * shadow_per_slot;
