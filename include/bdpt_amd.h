@@ -187,7 +187,10 @@ int bdpt_visible(bdpt_context* ctx, const bdpt_scene* scene, const double* pairs
  * pixels are written.  stats: optional, filled when BDPT_RENDER_COUNT_STATS is set. */
 int bdpt_render(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam,
                 const bdpt_render_params* params, double* framebuffer, bdpt_stats* stats);
-/* Same, framebuffer in device memory; returns after enqueueing on `stream` (hipStream_t or NULL). */
+/* Same, framebuffer in device memory; returns after enqueueing on `stream` (hipStream_t or NULL).
+ * The context keeps the per-sample path state of the batches in flight in one device allocation made at the first
+ * call and grown on demand: up to min(176 GB, 70 % of the free device memory) for frames large enough to use it
+ * (environment: BDPT_WF_BUDGET_GB, BDPT_WF_BATCH_LOG2).  One context renders one frame at a time. */
 int bdpt_render_device(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam,
                        const bdpt_render_params* params, void* d_framebuffer, void* stream);
 /* Counters of the last bdpt_render_device call that requested them (synchronises). */
