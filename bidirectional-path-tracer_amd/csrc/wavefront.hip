@@ -164,12 +164,14 @@ struct TopLdsMem {
 };
 
 // Box tests of the traversal hierarchy only have to be conservative, so they run in packed FP32 with
-// the rounding error carried explicitly.  Per axis the ray keeps inv = fl(1/d) and the pair
-// (c_min, c_max) = fl(-o/d) -/+ slack; the distances to the two planes of a box are then ONE packed fma,
-// (box_min, box_max) * inv + (c_min, c_max) for 1/d > 0 (pair swapped otherwise), giving a lower bound of
-// the distance to the near plane and an upper bound of the distance to the far plane:
-//   | fl(b*inv + c) - (b - o)/d |  <=  (|b| + |o| + |b - o|) * 2^-24 / |d| * (1 + tiny)  <=  slack
-// with slack = (bound + |o|) * 2^-21 / |d| (bound = largest |coordinate| of any box), four times the bound.
+// the rounding error carried explicitly.  Per axis the ray keeps inv ~ 1/d (FP32 reciprocal instruction, 1 ulp) and
+// the pair (c_min, c_max) = fl(-o * inv) -/+ slack; the distances to the two planes of a box are then ONE packed
+// fma, (box_min, box_max) * inv + (c_min, c_max) for 1/d > 0 (pair swapped otherwise), giving a lower bound of
+// the distance to the near plane and an upper bound of the distance to the far plane.  Against the exact
+// (b - o)/d the computed value is off by at most
+//   |b - o|/|d| * 1.5 * 2^-23  (d to FP32 and the reciprocal)  +  |o|/|d| * 2^-23  (o to FP32 and the product)
+//   + |t| * 2^-24  (the fma)   <=   (|b| + |o|) / |d| * 0.75 * 2^-21
+// and slack = (bound + |o|) * 2^-20 * |inv| (bound = largest |coordinate| of any box) is 2.6 times that.
 // A NaN (0 * inf, inf - inf: rays parallel to an axis) is dropped by min/max, i.e. that plane does not
 // constrain the interval - never a wrong cull.
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -177,17 +179,18 @@ struct RayF32 {
     f2 inv[3];      // (1/d, 1/d)
     f2 c[3];        // additive terms of the (min, max) planes
 };
-BDPT_DEV RayF32 ray_f32(V3 o, double ix, double iy, double iz, double bound) {
+BDPT_DEV RayF32 ray_f32(V3 o, V3 d, float bound) {
     RayF32 r;
-    const double oo[3] = {o.x, o.y, o.z}, ii[3] = {ix, iy, iz};
+    const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const float inv = (float)ii[a];
-        const float c = (float)(-(oo[a] * ii[a]));
-        const float slack = (float)((bound + __builtin_fabs(oo[a])) * 0x1p-21 * __builtin_fabs(ii[a])) * 1.0000002f;
+        const float inv = __builtin_amdgcn_rcpf((float)dd[a]);
+        const float of = (float)oo[a];
+        const float c = -(of * inv);
+        const float slack = (bound + __builtin_fabsf(of)) * 0x1p-20f * __builtin_fabsf(inv) * 1.000001f;
         r.inv[a] = (f2){inv, inv};
         // 1/d > 0: the min plane is the near one (gets -slack); 1/d < 0: the max plane is
-        r.c[a] = (ii[a] >= 0.0) ? (f2){c - slack, c + slack} : (f2){c + slack, c - slack};
+        r.c[a] = (inv >= 0.0f) ? (f2){c - slack, c + slack} : (f2){c + slack, c - slack};
     }
     return r;
 }
@@ -249,7 +252,8 @@ BDPT_DEV void sort2(double& a, double& b) {
 }
 
 // aabb::hit (aabb.h:41-66) of every bvh_node from `node` up to the root, with the interval [0.001, max_t]
-BDPT_DEV bool reference_reaches(const SceneDev& sc, uint32_t node, V3 o, double ix, double iy, double iz, double max_t) {
+BDPT_DEV bool reference_reaches(const SceneDev& sc, uint32_t node, V3 o, V3 d, double max_t) {
+    const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;       // aabb.h:48
     for (uint32_t n = node; n != kEndOfTree; n = sc.node_parent[n]) {
         const GpuNode nd = sc.nodes[n];
         double lo, hi;
@@ -270,6 +274,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                              uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk,
                              const int kLeafThreshold, const double coord_bound, double* lds_stack, const int kLdsStack,
                              const uint32_t first_base) {
+    const float bound_f32 = float_up(coord_bound);
     bool has = false;
     uint32_t slot = 0;
     int32_t cur = kPop;                 // interior record to visit next (when leaf_left == 0)
@@ -287,7 +292,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
     };
     unsigned long long tag = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
-    double ix = 0, iy = 0, iz = 0, closest = 0;
+    double closest = 0;
     RayF32 rf = {};
     HitLite h;
     h.t = 0; h.u = 0; h.v = 0; h.tri = -1;
@@ -333,8 +338,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                         tmax0 = kInf;
                     }
                     if (!SHADOW || tmax0 >= 0.0) {              // a negative max_t marks an unused queue entry
-                        ix = 1.0 / d.x; iy = 1.0 / d.y; iz = 1.0 / d.z;       // aabb.h:48, once per ray
-                        rf = ray_f32(o, ix, iy, iz, coord_bound);
+                        rf = ray_f32(o, d, bound_f32);
                         closest = tmax0;
                         cur = 0;
                         leaf_left = 0;
@@ -408,7 +412,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                         // interval (the far end point's own surface, t = max_t up to rounding) needs the check.
                         const double margin = 1e-9 * closest + 1e-12;
                         const bool at_an_end = (closest - t <= margin) || (t - 0.001 <= margin);
-                        if (!at_an_end || reference_reaches(sc, sc.sleaf[tr.pad], o, ix, iy, iz, closest)) { h.tri = tr.pad; done = true; leaf_left = 0; }
+                        if (!at_an_end || reference_reaches(sc, sc.sleaf[tr.pad], o, d, closest)) { h.tri = tr.pad; done = true; leaf_left = 0; }
                     }
                     // equal t: the reference keeps the triangle it visits later = larger position in
                     // its leaf order (tr.pad)
