@@ -242,6 +242,42 @@ def test_large_scene_uses_global_memory_path(scenes, ctx, oracle):
     sc.close()
 
 
+WF_SETTINGS = [
+    {"BDPT_WF_LDS_STACK": "0"},                                   # whole traversal stack in scratch
+    {"BDPT_WF_LDS_STACK": "2"},                                   # two entries in LDS, pushes straddle the border
+    {"BDPT_WF_LDS_STACK": "16", "BDPT_WF_LDS_KB": "1"},
+    {"BDPT_WF_BATCH_LOG2": "12", "BDPT_WF_STREAMS": "3"},         # many small batches
+    {"BDPT_WF_STREAMS": "1"},
+    {"BDPT_WF_CHUNK": "16", "BDPT_WF_BLOCKS_PER_CU": "1"},
+    {"BDPT_WF_REFILL": "1", "BDPT_WF_LEAF": "1"},
+    {"BDPT_WF_REFILL": "64", "BDPT_WF_LEAF": "64"},
+    {"BDPT_WF_BUDGET_GB": "1"},
+]
+
+
+@pytest.mark.parametrize("lds_scene", [True, False])
+def test_image_does_not_depend_on_launch_settings(scenes, ctx, lds_scene, monkeypatch):
+    """Batch size, streams in flight, queue chunks, occupancy and where the traversal stack lives only change the
+    schedule: every setting returns the bits of the default one (small scene staged in LDS / larger one in global
+    memory with a stack deeper than its LDS part)."""
+    flat = scenes.cornell_box(48, 16, 8)
+    if not lds_scene:
+        mat = flat.add_material(scenes.Material(scenes.LAMBERTIAN, (.4, .6, .3)))
+        glass = flat.add_material(scenes.Material(scenes.DIELECTRIC, (1, 1, 1), ior=1.5))
+        for k in range(3):
+            scenes.add_uv_sphere(flat, (150 + 120 * k, 90 + 40 * k, 200 + 60 * k), 70.0, glass if k == 1 else mat, 16, 32)
+    sc = ctx.scene(flat)
+    cam = capi.camera_initialize(flat.camera)
+    want = sc.render(cam, seed=11)
+    assert want.max() > 0
+    for setting in WF_SETTINGS:
+        with monkeypatch.context() as m:
+            for k, v in setting.items():
+                m.setenv(k, v)
+            assert_bit_equal(sc.render(cam, seed=11), want, str(setting))
+    sc.close()
+
+
 def test_bad_arguments_are_rejected(scenes, ctx):
     flat = scenes.cornell_box(8, 4, 3)
     sc = ctx.scene(flat)
