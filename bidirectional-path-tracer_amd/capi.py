@@ -82,6 +82,7 @@ EXPORTED_SYMBOLS = [
     "bdpt_render_get_kernel_ms", "bdpt_render_get_stage_ms",
     "bdpt_colors_to_rgb8", "bdpt_colors_to_rgb8_device", "bdpt_device_sincos", "bdpt_device_random_doubles",
     "bdpt_device_arith", "bdpt_scene_file_load", "bdpt_scene_file_destroy", "bdpt_scene_file_get", "bdpt_write_png", "bdpt_debug_yaml_to_json",
+    "bdpt_reduce_framebuffer",
 ]
 
 _lib = None
@@ -130,12 +131,18 @@ def load_library() -> C.CDLL:
     lib.bdpt_scene_file_destroy.argtypes = [vp]
     lib.bdpt_scene_file_get.argtypes = [vp, C.POINTER(SceneFileView)]
     lib.bdpt_write_png.argtypes = [C.c_char_p, vp, C.c_int32, C.c_int32]
+    lib.bdpt_reduce_framebuffer.argtypes = [vp, vp, C.c_uint64, vp]
     lib.bdpt_debug_yaml_to_json.argtypes = [C.c_char_p, C.c_char_p, u64]
     for name in EXPORTED_SYMBOLS:
         if name != "bdpt_last_error":
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
+
+
+def reduce_framebuffer(rccl_comm: int, d_framebuffer: int, n_doubles: int, stream: int = 0) -> None:
+    """Sum of the ranks' framebuffers in place (one all-reduce); `rccl_comm` is an ncclComm_t as an integer."""
+    _check(load_library().bdpt_reduce_framebuffer(C.c_void_p(rccl_comm), C.c_void_p(d_framebuffer), n_doubles, C.c_void_p(stream)))
 
 
 def _check(rc: int) -> None:

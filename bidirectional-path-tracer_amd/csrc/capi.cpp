@@ -1,5 +1,7 @@
 // C ABI (include/bdpt_amd.h) over the HIP kernels: contexts, scene upload, render / trace entry points.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -730,6 +732,29 @@ int bdpt_render(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
         std::memset(stats, 0, sizeof *stats);
         if (params->flags & (BDPT_RENDER_COUNT_STATS | BDPT_RENDER_COUNT_WORK)) return bdpt_render_get_stats(ctx, stats);
     }
+    return BDPT_OK;
+}
+
+int bdpt_reduce_framebuffer(void* rccl_comm, void* d_framebuffer, uint64_t n_doubles, void* stream) {
+    if (!rccl_comm || !d_framebuffer) return fail(BDPT_ERR_INVALID_ARGUMENT, "bdpt_reduce_framebuffer: null communicator or framebuffer");
+    // resolved at run time: the library itself does not link RCCL, so hosts that never call this do not load it
+    using AllReduce = decltype(&ncclAllReduce);
+    using ErrorString = decltype(&ncclGetErrorString);
+    static AllReduce all_reduce = nullptr;
+    static ErrorString error_string = nullptr;
+    if (!all_reduce) {
+        void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return fail(BDPT_ERR_UNSUPPORTED, std::string("bdpt_reduce_framebuffer: cannot load RCCL: ") + dlerror());
+        error_string = reinterpret_cast<ErrorString>(dlsym(lib, "ncclGetErrorString"));
+        all_reduce = reinterpret_cast<AllReduce>(dlsym(lib, "ncclAllReduce"));
+        if (!all_reduce) return fail(BDPT_ERR_UNSUPPORTED, "bdpt_reduce_framebuffer: ncclAllReduce not found in the RCCL library");
+    }
+    if (n_doubles == 0) return BDPT_OK;
+    const ncclResult_t r = all_reduce(d_framebuffer, d_framebuffer, (size_t)n_doubles, ncclFloat64, ncclSum,
+                                      static_cast<ncclComm_t>(rccl_comm), static_cast<hipStream_t>(stream));
+    if (r != ncclSuccess)
+        return fail(BDPT_ERR_DEVICE, std::string("ncclAllReduce: ") + (error_string ? error_string(r) : "error"));
     return BDPT_OK;
 }
 

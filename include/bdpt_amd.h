@@ -211,6 +211,14 @@ int bdpt_colors_to_rgb8(const double* framebuffer, int32_t width, int32_t height
 int bdpt_colors_to_rgb8_device(bdpt_context* ctx, const void* d_framebuffer, int32_t width, int32_t height,
                                int32_t samples_per_pixel, void* d_out_rgb, void* stream);
 
+/* Multi-GPU: the ranks render disjoint pixel sets (shard_index / shard_count of bdpt_render_params) into zeroed
+ * full-size framebuffers; this sums them in place on every rank with one all-reduce over xGMI, enqueued on
+ * `stream` after the render.  No counterpart in the reference (one process, one framebuffer, camera.h:124); it
+ * stands where the reference's worker threads write their rows into the shared framebuffer.  `rccl_comm` is the
+ * caller's ncclComm_t (one process per GPU).  The RCCL library is looked up at the first call; a host that
+ * already reduces through its own framework (e.g. torch.distributed) does not need this entry point. */
+int bdpt_reduce_framebuffer(void* rccl_comm, void* d_framebuffer, uint64_t n_doubles, void* stream);
+
 /* ---- scene files and image output (host only, no GPU work) ---- */
 /* load_scene_from_yaml(path), src/scene/scene_loader.h:480-523, without yaml-cpp: the camera block (:427-476),
  * the named materials (:173-188, build_material :101-170), and the surfaces `TriMesh` (:244-272), `Sphere`

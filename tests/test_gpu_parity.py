@@ -242,6 +242,44 @@ def test_large_scene_uses_global_memory_path(scenes, ctx, oracle):
     sc.close()
 
 
+def test_reduce_framebuffer_over_rccl(ctx):
+    """bdpt_reduce_framebuffer is one ncclAllReduce(sum, double) on the caller's communicator.  One GPU here, so
+    the communicator has one rank and the sum must return the buffer unchanged; wrong arguments are refused."""
+    import ctypes as C
+    import torch
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("no RCCL library on this machine")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        fb = torch.arange(3 * 64 * 48, dtype=torch.float64, device="cuda") * 0.25 - 7.0
+        want = fb.clone()
+        capi.reduce_framebuffer(comm.value, fb.data_ptr(), fb.numel(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(fb, want)
+        capi.reduce_framebuffer(comm.value, fb.data_ptr(), 0)
+        with pytest.raises(capi.BdptError):
+            capi.reduce_framebuffer(0, fb.data_ptr(), fb.numel())
+        with pytest.raises(capi.BdptError):
+            capi.reduce_framebuffer(comm.value, 0, fb.numel())
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
 WF_SETTINGS = [
     {"BDPT_WF_LDS_STACK": "0"},                                   # whole traversal stack in scratch
     {"BDPT_WF_LDS_STACK": "2"},                                   # two entries in LDS, pushes straddle the border
