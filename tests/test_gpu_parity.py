@@ -222,6 +222,52 @@ def test_spp_one_and_depth_zero(scenes, ctx, oracle):
     sc.close(); sc2.close()
 
 
+def _moved(flat, scale, shift):
+    """The scene and its camera scaled about the origin and then translated."""
+    import copy
+    out = copy.deepcopy(flat)
+    out.vertices = [[v[k] * scale + shift[k % 3] for k in range(9)] for v in flat.vertices]
+    out.camera.lookfrom = tuple(flat.camera.lookfrom[k] * scale + shift[k] for k in range(3))
+    out.camera.lookat = tuple(flat.camera.lookat[k] * scale + shift[k] for k in range(3))
+    return out
+
+
+@pytest.mark.parametrize("scale,shift", [(1e-3, (0.0, 0.0, 0.0)), (37.0, (0.0, 0.0, 0.0)), (1.0, (1.0e5, -2.0e5, 3.0e4)),
+                                         (1e4, (-7.0e6, 1.0e6, 5.0e6))])
+def test_scene_scale_and_position(scenes, ctx, oracle, scale, shift):
+    """Coordinates far from the origin or of a very different magnitude widen the FP32 box tests of the traversal
+    hierarchy (their error allowance grows with the largest coordinate) but must not change a bit of the image:
+    production pipeline = single-kernel path = oracle."""
+    flat = _moved(scenes.materials_showcase(24, 16, 6), scale, shift)
+    sc = ctx.scene(flat)
+    cam = capi.camera_initialize(flat.camera)
+    fb = sc.render(cam, seed=5)
+    ofb, _, _ = oracle.scene(flat).render(cam.as_array(), 24, cam.sqrt_spp, 6, 5, (0, 0, 24, cam.image_height))
+    assert_bit_equal(fb, ofb, "moved scene, wavefront")
+    assert_bit_equal(sc.render(cam, seed=5, megakernel=True), ofb, "moved scene, single kernel")
+    sc.close()
+
+
+def test_one_triangle_and_one_light(scenes, ctx, oracle):
+    """The smallest scenes: a single triangle (one leaf, wrapped so that record 0 exists) and two triangles."""
+    for n in (1, 2):
+        flat = scenes.FlatScene()
+        light = flat.add_material(scenes.Material(scenes.DIFFUSE_LIGHT, (4, 4, 4)))
+        white = flat.add_material(scenes.Material(scenes.LAMBERTIAN, (.7, .7, .7)))
+        flat.add_triangle((-1, 2, -1), (1, 2, -1), (0, 2, 1), light)      # faces down
+        if n == 2:
+            flat.add_triangle((-3, 0, -3), (0, 0, 3), (3, 0, -3), white)
+        flat.camera = scenes.Camera(aspect_ratio=1.0, image_width=16, samples_per_pixel=16, max_depth=4,
+                                    background=(0.1, 0.2, 0.3), vfov=60, lookfrom=(0, 1, -4), lookat=(0, 1, 0), vup=(0, 1, 0))
+        sc = ctx.scene(flat)
+        cam = capi.camera_initialize(flat.camera)
+        fb = sc.render(cam, seed=2)
+        ofb, _, _ = oracle.scene(flat).render(cam.as_array(), 16, cam.sqrt_spp, 4, 2, (0, 0, 16, cam.image_height))
+        assert_bit_equal(fb, ofb, "%d triangle(s)" % n)
+        assert_bit_equal(sc.render(cam, seed=2, megakernel=True), ofb, "%d triangle(s), single kernel" % n)
+        sc.close()
+
+
 def test_large_scene_uses_global_memory_path(scenes, ctx, oracle):
     """More nodes + triangles than the LDS staging limit: the traversal reads the tables from
     global memory; results are still the oracle's."""
