@@ -17,8 +17,9 @@ Rank 0 prints ONE JSON line; at N = 1 it also carries
   "roofline"     : algorithmic bytes of the render kernel (counted by the kernel itself on a
                    1/8 row sample, scaled to a full launch) / its launch time measured with HIP
                    events on the launch's own stream, against the 8 TB/s HBM peak
-  "cpu_baseline" : the CPU oracle (restatement of the reference path, FP64, same streams) timed on
-                   the host cores over a bounded pixel lattice of the same workload.
+  "cpu_baseline" : the reference's own headers (compiled in place into oracle/_ref, kind "reference") timed on the
+                   host cores over a bounded pixel lattice of the same workload, with the CPU oracle (restatement of
+                   the reference path, FP64, same streams; kind "port") beside it under "port".
 """
 import argparse
 import importlib
@@ -89,8 +90,15 @@ def cpu_worker(args):
     print(json.dumps({"pixels": done, "seconds": dt, "spp_used": sqrt_spp * sqrt_spp}))
 
 
+REF_HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness_glibc")
+
+
 def run_cpu_baseline(workload, seed, seconds, flat):
-    import math
+    """The reference's own code (its headers compiled in place into oracle/_ref/ref_harness_glibc: camera::get_ray /
+    ray_color on a bvh_node, per-(pixel, sample) random streams, glibc libm) timed on the host cores; the CPU
+    restatement (oracle/) beside it.  One single-threaded process per core, each over its own share of a pixel
+    lattice spread over the frame, so the reference's shared atomics and shared generator cost it nothing here."""
+    import tempfile
     cores = len(os.sched_getaffinity(0))
     cores = max(1, min(cores, 16))
     W = flat.camera.image_width
@@ -100,30 +108,49 @@ def run_cpu_baseline(workload, seed, seconds, flat):
     if W < nx * 2 or H < ny * 2:
         nx, ny = max(1, W // 4), max(1, H // 4)
     lattice = [(int((a + 0.5) * W / nx), int((b + 0.5) * H / ny)) for b in range(ny) for a in range(nx)]
-    # interleave so that each worker's share is itself spread over the frame
-    procs = []
-    for w in range(cores):
-        mine = lattice[w::cores]
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--workload", workload, "--seed", str(seed),
-               "--cpu-seconds", str(seconds), "--cpu-pixels", ";".join("%d,%d" % p for p in mine)]
-        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    results = []
-    for p in procs:
-        out, err = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError("cpu baseline worker failed: " + err[-2000:])
-        results.append(json.loads(out.strip().splitlines()[-1]))
-    spp_used = results[0]["spp_used"]
+    # fixed scattering of the order, so that whatever prefix the workers finish before the deadline is itself spread
+    # evenly over the frame (4099 is prime and does not divide the lattice size)
+    lattice = [lattice[(k * 4099) % len(lattice)] for k in range(len(lattice))] if len(lattice) % 4099 else lattice
     depth = flat.camera.max_depth
-    # each worker ran alone on its core: aggregate rate = sum of the per-core rates
-    rate = sum(r["pixels"] * spp_used * depth / r["seconds"] for r in results) / 1e6
-    total_px = sum(r["pixels"] for r in results)
-    return {
-        "value": rate, "unit": "Msamples/s", "cores": cores, "kind": "port",
-        "sample": "%d pixels of a %dx%d lattice over the %dx%d frame at the full %d spp / depth %d, one single-threaded "
-                  "oracle process per core for <= %.0f s; compiled with g++ -O2 -ffp-contract=off" %
-                  (total_px, nx, ny, W, H, spp_used, depth, seconds),
-    }
+
+    def run(make_cmd, secs):
+        # interleave so that each worker's share is itself spread over the frame
+        procs = []
+        for w in range(cores):
+            mine = ";".join("%d,%d" % p for p in lattice[w::cores])
+            procs.append(subprocess.Popen(make_cmd(mine, secs), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        results = []
+        for p in procs:
+            out, err = p.communicate()
+            if p.returncode != 0:
+                raise RuntimeError("cpu baseline worker failed: " + err[-2000:])
+            results.append(json.loads(out.strip().splitlines()[-1]))
+        spp_used = results[0]["spp_used"]
+        # each worker ran alone on its core: aggregate rate = sum of the per-core rates
+        rate = sum(r["pixels"] * spp_used * depth / r["seconds"] for r in results) / 1e6
+        return rate, sum(r["pixels"] for r in results), spp_used
+
+    def sample_text(total_px, spp_used, secs, what):
+        return ("%d pixels of a %dx%d lattice over the %dx%d frame at the full %d spp / depth %d, one single-threaded "
+                "%s process per core for <= %.0f s; g++ -O2 -ffp-contract=off" % (total_px, nx, ny, W, H, spp_used, depth, what, secs))
+
+    port_secs = seconds if not os.path.exists(REF_HARNESS) else max(5.0, seconds / 2)
+    rate, total_px, spp_used = run(lambda mine, secs: [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--workload", workload,
+                                                       "--seed", str(seed), "--cpu-seconds", str(secs), "--cpu-pixels", mine], port_secs)
+    port = {"value": rate, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": sample_text(total_px, spp_used, port_secs, "oracle (CPU restatement)")}
+    if not os.path.exists(REF_HARNESS):
+        return port
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        f.write(flat.to_bytes())
+        scene_path = f.name
+    try:
+        rate, total_px, spp_used = run(lambda mine, secs: [REF_HARNESS, scene_path, "bench", str(seed), str(secs), mine], seconds)
+    finally:
+        os.unlink(scene_path)
+    return {"value": rate, "unit": "Msamples/s", "cores": cores, "kind": "reference",
+            "sample": sample_text(total_px, spp_used, seconds, "reference-harness (the reference's headers, scene build excluded)"),
+            "port": port}
 
 
 # ------------------------------------------------------------------------------------------ main

@@ -332,6 +332,49 @@ int main(int argc, char** argv) {
     }
 #endif
 
+#ifndef HARNESS_NO_SHIM
+    if (op == "bench") {
+        // argv: seed seconds "i,j;i,j;..."  -> one JSON line: pixels finished and the seconds they took (scene loading
+        // and the BVH build are outside).  The reference's own per-pixel loop (camera.h:116-124) over the listed
+        // pixels, single-threaded, until the list or the time runs out.
+        uint64_t seed = strtoull(argv[3], nullptr, 10);
+        const double seconds = atof(argv[4]);
+        std::vector<std::pair<int, int>> pixels;
+        for (const char* c = argv[5]; *c;) {
+            char* end;
+            const long i = strtol(c, &end, 10);
+            if (*end != ',') break;
+            const long j = strtol(end + 1, &end, 10);
+            pixels.push_back({(int)i, (int)j});
+            c = (*end == ';') ? end + 1 : end;
+            if (*end != ';') break;
+        }
+        const int W = cam.image_width;
+        harness_rng().engine = 0;
+        double sink = 0;
+        size_t done = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        double dt = 0;
+        for (const auto& px : pixels) {
+            const int i = px.first, j = px.second;
+            color pixel_color(0, 0, 0);
+            for (int s_j = 0; s_j < cam.sqrt_spp; s_j++)
+                for (int s_i = 0; s_i < cam.sqrt_spp; s_i++) {
+                    harness_rng().stream.key = orng_stream_key(seed, (uint64_t)j * W + i, (uint64_t)s_j * cam.sqrt_spp + s_i);
+                    harness_rng().stream.counter = 0;
+                    ray r = cam.get_ray(i, j, s_i, s_j);
+                    pixel_color += cam.ray_color(r, cam.max_depth, *b.bvh, lights);
+                }
+            sink += pixel_color[0] + pixel_color[1] + pixel_color[2];
+            done++;
+            dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt > seconds) break;
+        }
+        printf("{\"pixels\": %zu, \"seconds\": %.6f, \"spp_used\": %d, \"checksum\": %.17g}\n", done, dt, cam.sqrt_spp * cam.sqrt_spp, sink);
+        return 0;
+    }
+#endif
+
     if (op == "render_serial") {   // the reference's own global serial RNG; argv[3] out.bin
 #ifndef HARNESS_NO_SHIM
         harness_rng().engine = 1;
