@@ -104,7 +104,7 @@ def run_cpu_baseline(workload, seed, seconds, flat):
     W = flat.camera.image_width
     H = max(1, int(W / flat.camera.aspect_ratio))
     # lattice of pixels spread evenly over the frame; workers take them round-robin and stop at the deadline
-    nx, ny = 128, 72
+    nx, ny = 192, 108
     if W < nx * 2 or H < ny * 2:
         nx, ny = max(1, W // 4), max(1, H // 4)
     lattice = [(int((a + 0.5) * W / nx), int((b + 0.5) * H / ny)) for b in range(ny) for a in range(nx)]
