@@ -40,11 +40,13 @@ class CameraPublic(C.Structure):
 class CameraState(C.Structure):
     _fields_ = [("center", C.c_double * 3), ("pixel00_loc", C.c_double * 3), ("pixel_delta_u", C.c_double * 3),
                 ("pixel_delta_v", C.c_double * 3), ("background", C.c_double * 3), ("image_width", C.c_int32),
-                ("image_height", C.c_int32), ("sqrt_spp", C.c_int32), ("max_depth", C.c_int32)]
+                ("image_height", C.c_int32), ("sqrt_spp", C.c_int32), ("max_depth", C.c_int32),
+                ("defocus_disk_u", C.c_double * 3), ("defocus_disk_v", C.c_double * 3), ("defocus_angle", C.c_double)]
 
     def as_array(self) -> np.ndarray:
-        """center pixel00 du dv background as 15 doubles (the layout the oracle takes)."""
-        return np.array([*self.center, *self.pixel00_loc, *self.pixel_delta_u, *self.pixel_delta_v, *self.background])
+        """center pixel00 du dv background disk_u disk_v defocus_angle as 22 doubles (the layout the oracle takes)."""
+        return np.array([*self.center, *self.pixel00_loc, *self.pixel_delta_u, *self.pixel_delta_v, *self.background,
+                         *self.defocus_disk_u, *self.defocus_disk_v, self.defocus_angle])
 
 
 class RenderParams(C.Structure):

@@ -76,6 +76,8 @@ struct GpuCamera {
     double background[3];
     double recip_sqrt_spp;
     int32_t width, height, sqrt_spp, max_depth;
+    double disk_u[3], disk_v[3];    // defocus disk, used when defocus_angle > 0
+    double defocus_angle;
 };
 
 struct SceneDev {

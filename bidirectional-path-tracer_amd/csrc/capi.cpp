@@ -133,6 +133,8 @@ GpuCamera to_gpu_camera(const bdpt_camera_state& c) {
         g.center[k] = c.center[k]; g.pixel00[k] = c.pixel00_loc[k]; g.du[k] = c.pixel_delta_u[k];
         g.dv[k] = c.pixel_delta_v[k]; g.background[k] = c.background[k];
     }
+    for (int k = 0; k < 3; k++) { g.disk_u[k] = c.defocus_disk_u[k]; g.disk_v[k] = c.defocus_disk_v[k]; }
+    g.defocus_angle = c.defocus_angle;
     g.recip_sqrt_spp = 1.0 / c.sqrt_spp;        // camera.h:166
     g.width = c.image_width; g.height = c.image_height; g.sqrt_spp = c.sqrt_spp; g.max_depth = c.max_depth;
     return g;

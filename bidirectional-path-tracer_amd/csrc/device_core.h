@@ -459,12 +459,23 @@ BDPT_DEV V3 connect(const Mem& mem, const SceneDev& sc, const Vertex& cv, const 
     return pair_contribution(cv, lv, g, f_cam, f_light);
 }
 
-// camera::get_ray, src/camera.h:199-223 (defocus disabled): three draws, the third (ray_time) unused
+// camera::get_ray, src/camera.h:199-223: two draws for the stratum offset, the defocus disk sample when
+// defocus_angle > 0 (random_in_unit_disk, vec3.h:113-119: the y argument is drawn before the x argument - argument
+// evaluation order of the compiler that built the pinned reference), one draw for ray_time (unused)
 BDPT_DEV void camera_ray(const GpuCamera& cam, int i, int j, int s_i, int s_j, Rng& rng, V3& origin, V3& dir) {
     double px = ((s_i + rng.next()) * cam.recip_sqrt_spp) - 0.5;
     double py = ((s_j + rng.next()) * cam.recip_sqrt_spp) - 0.5;
-    origin = ld3(cam.center);
     V3 pixel_sample = add(add(ld3(cam.pixel00), scl(i + px, ld3(cam.du))), scl(j + py, ld3(cam.dv)));
+    origin = ld3(cam.center);
+    if (cam.defocus_angle > 0) {                                               // camera.h:230-234
+        double dx, dy;
+        for (;;) {
+            dy = rng.next(-1, 1);
+            dx = rng.next(-1, 1);
+            if (dx * dx + dy * dy + 0.0 * 0.0 < 1) break;
+        }
+        origin = add(add(ld3(cam.center), scl(dx, ld3(cam.disk_u))), scl(dy, ld3(cam.disk_v)));
+    }
     dir = sub(pixel_sample, origin);
     (void)rng.next();                                                          // ray_time, camera.h:210
 }

@@ -493,7 +493,6 @@ std::string camera_initialize(const bdpt_camera_public& c, bdpt_camera_state& ou
     if (c.image_width <= 0) return "image_width must be positive";
     if (!(c.aspect_ratio > 0)) return "aspect_ratio must be positive";
     if (c.samples_per_pixel < 1) return "samples_per_pixel must be at least 1";
-    if (c.defocus_angle > 0) return "defocus blur is not supported (the reference's loader disables it)";
     const double pi = 3.1415926535897932385;          // src/main.h:20
     int image_height = int(c.image_width / c.aspect_ratio);
     image_height = (image_height < 1) ? 1 : image_height;
@@ -533,6 +532,13 @@ std::string camera_initialize(const bdpt_camera_public& c, bdpt_camera_state& ou
         out.center[k] = lf[k];
         out.background[k] = c.background[k];
     }
+    // camera.h:193-196: defocus_radius = focus_dist * tan(degrees_to_radians(defocus_angle / 2)); u * r == r * u
+    const double defocus_radius = c.focus_dist * std::tan((c.defocus_angle / 2) * pi / 180.0);
+    for (int k = 0; k < 3; k++) {
+        out.defocus_disk_u[k] = defocus_radius * u[k];
+        out.defocus_disk_v[k] = defocus_radius * v[k];
+    }
+    out.defocus_angle = c.defocus_angle;
     out.image_width = c.image_width;
     out.image_height = image_height;
     out.sqrt_spp = sqrt_spp;

@@ -212,6 +212,15 @@ def cornell_box(image_width: int = 512, samples_per_pixel: int = 256, max_depth:
     return s
 
 
+def showcase_with_defocus(image_width: int = 32, samples_per_pixel: int = 16, max_depth: int = 6) -> FlatScene:
+    """materials_showcase seen through a thin lens: defocus_angle 4 degrees, focus distance 7
+    (/root/reference/src/camera.h:193-196,208,230-234)."""
+    s = materials_showcase(image_width, samples_per_pixel, max_depth)
+    s.camera.defocus_angle = 4.0
+    s.camera.focus_dist = 7.0
+    return s
+
+
 def materials_showcase(image_width: int = 48, samples_per_pixel: int = 16, max_depth: int = 8) -> FlatScene:
     """Small closed room that exercises every material branch of the hot path: lambertian walls,
     a fuzzy metal box, a mirror (fuzz 0) floor, a dielectric box (ior 1.5) with a nested dielectric

@@ -49,8 +49,8 @@ typedef struct bdpt_material {
     double ior;
 } bdpt_material;
 
-/* Public camera fields, src/camera.h:26-38 (defocus blur is disabled by the reference's
- * loader, src/scene/scene_loader.h:463, and is not supported: defocus_angle must be <= 0). */
+/* Public camera fields, src/camera.h:26-38.  defocus_angle > 0 turns the defocus disk on (camera.h:208,
+ * 230-234); the reference's scene loader always sets it to 0 (src/scene/scene_loader.h:463). */
 typedef struct bdpt_camera_public {
     double lookfrom[3];
     double lookat[3];
@@ -77,6 +77,9 @@ typedef struct bdpt_camera_state {
     int32_t image_height;
     int32_t sqrt_spp;        /* int(sqrt(samples_per_pixel)); sqrt_spp^2 samples are taken (camera.h:164) */
     int32_t max_depth;
+    double defocus_disk_u[3];   /* camera.h:193-196 */
+    double defocus_disk_v[3];
+    double defocus_angle;       /* <= 0: rays start at `center` (camera.h:208) */
 } bdpt_camera_state;
 
 /* One render call = the worker loop of camera::render (src/camera.h:111-129) over the

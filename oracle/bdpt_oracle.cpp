@@ -332,6 +332,8 @@ inline double reflectance(double cosine, double refraction_index) {   // materia
 // ---------------------------------------------------------------- integrator (src/camera.h)
 struct Camera {                 // the private state camera::initialize computes (camera.h:148-158)
     V3 center, pixel00_loc, pixel_delta_u, pixel_delta_v, background;
+    V3 defocus_disk_u, defocus_disk_v;
+    double defocus_angle;
 };
 
 struct PathVertex {             // camera.h:236-243
@@ -606,13 +608,23 @@ V3 path_trace_color(const oracle_scene& s, const Camera& cam, const std::vector<
     return add(color_from_emission, color_from_scatter);
 }
 
-// camera.h:199-223 (defocus_angle <= 0: the loader forces it to 0, src/scene/scene_loader.h:463)
+// camera.h:199-223; defocus_disk_sample camera.h:230-234 with random_in_unit_disk, vec3.h:113-119 (the second
+// argument of vec3(random_double(-1,1), random_double(-1,1), 0) is evaluated first by the pinned compiler)
 Ray get_ray(const Camera& cam, int i, int j, int s_i, int s_j, double recip_sqrt_spp, Rng& rng) {
     double px = ((s_i + rng.next()) * recip_sqrt_spp) - 0.5;
     double py = ((s_j + rng.next()) * recip_sqrt_spp) - 0.5;
     V3 pixel_sample = add(add(cam.pixel00_loc, scl(i + px, cam.pixel_delta_u)), scl(j + py, cam.pixel_delta_v));
     Ray r;
     r.o = cam.center;
+    if (cam.defocus_angle > 0) {
+        double dx, dy;
+        for (;;) {
+            dy = -1 + (1 - -1) * rng.next();            // main.h:36-39
+            dx = -1 + (1 - -1) * rng.next();
+            if (dx * dx + dy * dy + 0.0 * 0.0 < 1) break;
+        }
+        r.o = add(add(cam.center, scl(dx, cam.defocus_disk_u)), scl(dy, cam.defocus_disk_v));
+    }
     r.d = sub(pixel_sample, r.o);
     (void)rng.next();   // ray_time (camera.h:210): drawn, never used
     return r;
@@ -625,6 +637,9 @@ Camera unpack_camera(const double* c) {
     cam.pixel_delta_u = mk(c[6], c[7], c[8]);
     cam.pixel_delta_v = mk(c[9], c[10], c[11]);
     cam.background = mk(c[12], c[13], c[14]);
+    cam.defocus_disk_u = mk(c[15], c[16], c[17]);
+    cam.defocus_disk_v = mk(c[18], c[19], c[20]);
+    cam.defocus_angle = c[21];
     return cam;
 }
 
@@ -753,6 +768,12 @@ void oracle_camera_initialize(const double* pub, int32_t image_width, int32_t sa
     out[3] = pixel00_loc.x; out[4] = pixel00_loc.y; out[5] = pixel00_loc.z;
     out[6] = pixel_delta_u.x; out[7] = pixel_delta_u.y; out[8] = pixel_delta_u.z;
     out[9] = pixel_delta_v.x; out[10] = pixel_delta_v.y; out[11] = pixel_delta_v.z;
+    // camera.h:193-196; pub[12] = defocus_angle
+    double defocus_radius = focus_dist * std::tan((pub[12] / 2) * kPi / 180.0);
+    V3 disk_u = scl(defocus_radius, u), disk_v = scl(defocus_radius, v);
+    out[12] = disk_u.x; out[13] = disk_u.y; out[14] = disk_u.z;
+    out[15] = disk_v.x; out[16] = disk_v.y; out[17] = disk_v.z;
+    out[18] = pub[12];
     *image_height_out = image_height;
     *sqrt_spp_out = sqrt_spp;
 }

@@ -56,7 +56,7 @@ void oracle_visible(const oracle_scene* s, const double* pairs, uint64_t n, doub
 
 /* The worker loop of camera::render (src/camera.h:116-124) over the pixel rectangle [x0,x1) x [y0,y1)
  * of a W-wide image, each (pixel, sample) on its own counter-based stream (oracle_rng.h).
- * camera: center pixel00_loc pixel_delta_u pixel_delta_v background (15 doubles).
+ * camera: center pixel00_loc pixel_delta_u pixel_delta_v background defocus_disk_u defocus_disk_v defocus_angle (22 doubles).
  * fb_out: (y1-y0)*(x1-x0)*3 doubles, the per-pixel SUM over samples.
  * per_sample_out (optional): 4 doubles per sample (r g b draws), pixel-major then s_j, s_i.
  * stats (optional): 7 BvhStats counters, then total RNG draws, then shadow rays, then connection pairs evaluated. */

@@ -203,6 +203,8 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 3; k++) o.push_back(cam.pixel_delta_v[k]);
         o.push_back(cam.image_height);
         o.push_back(cam.sqrt_spp);
+        for (int k = 0; k < 3; k++) o.push_back(cam.defocus_disk_u[k]);
+        for (int k = 0; k < 3; k++) o.push_back(cam.defocus_disk_v[k]);
         write_file(argv[3], o.data(), o.size() * 8);
         return 0;
     }

@@ -171,6 +171,10 @@ def main():
     for b in (HARNESS, HARNESS_GLIBC, HARNESS_NOSHIM):
         if not os.path.exists(b):
             sys.exit("missing %s - run `make -C oracle ref` first" % b)
+    if "--only-defocus" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            golden_for("showcase_defocus", scenes.showcase_with_defocus(32, 16, 6), tmp, seed=13, sample_crop=(8, 8, 24, 24))
+        return
     if "--only-unidirectional" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
             unidirectional_fixtures(tmp)
@@ -196,6 +200,8 @@ def main():
         golden_for("cornell_d2", scenes.cornell_box(16, 5, 2), tmp, seed=2)
         golden_for("cornell_d12", scenes.cornell_box(16, 2, 12), tmp, seed=5, sample_crop=(0, 0, 16, 16))
         golden_for("showcase_d20", scenes.materials_showcase(24, 4, 20), tmp, seed=9, sample_crop=(0, 0, 24, 16))
+        # thin-lens camera (defocus_angle > 0)
+        golden_for("showcase_defocus", scenes.showcase_with_defocus(32, 16, 6), tmp, seed=13, sample_crop=(8, 8, 24, 24))
 
         # the unshimmed reference (real src/main.h: one serial default-seeded mt19937)
         sc = scenes.cornell_box(16, 4, 5)

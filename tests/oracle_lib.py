@@ -21,6 +21,14 @@ def build_if_needed():
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True, capture_output=True)
 
 
+def _cam22(cam):
+    """The oracle's camera layout is 22 doubles; shorter arrays (no defocus fields) are padded with zeros."""
+    out = np.zeros(22)
+    cam = np.asarray(cam, dtype=np.float64)
+    out[:len(cam)] = cam
+    return out
+
+
 class OracleScene:
     def __init__(self, lib, flat):
         self.lib = lib
@@ -80,7 +88,7 @@ class OracleScene:
         stats = np.zeros(10, dtype=np.uint64)
         n_s = (y1 - y0) * (x1 - x0) * sqrt_spp * sqrt_spp
         smp = np.zeros((n_s, 4)) if per_sample else None
-        self.lib.oracle_render(self.h, np.ascontiguousarray(cam15, dtype=np.float64), W, sqrt_spp, max_depth,
+        self.lib.oracle_render(self.h, _cam22(cam15), W, sqrt_spp, max_depth,
                                int(seed), x0, y0, x1, y1, fb, smp.ctypes.data if per_sample else None, stats)
         return fb, stats, smp
 
@@ -88,14 +96,14 @@ class OracleScene:
         x0, y0, x1, y1 = [int(v) for v in rect]
         fb = np.zeros((y1 - y0, x1 - x0, 3))
         stats = np.zeros(10, dtype=np.uint64)
-        self.lib.oracle_render_unidirectional(self.h, np.ascontiguousarray(cam15, dtype=np.float64), W, sqrt_spp, max_depth,
+        self.lib.oracle_render_unidirectional(self.h, _cam22(cam15), W, sqrt_spp, max_depth,
                                               int(seed), x0, y0, x1, y1, fb, stats)
         return fb, stats
 
     def render_serial_mt(self, cam15, W, H, sqrt_spp, max_depth):
         fb = np.zeros((H, W, 3))
         stats = np.zeros(10, dtype=np.uint64)
-        self.lib.oracle_render_serial_mt(self.h, np.ascontiguousarray(cam15, dtype=np.float64), W, H, sqrt_spp,
+        self.lib.oracle_render_serial_mt(self.h, _cam22(cam15), W, H, sqrt_spp,
                                          max_depth, fb, stats)
         return fb, stats
 
@@ -132,12 +140,14 @@ class Oracle:
         return OracleScene(self.lib, flat)
 
     def camera_initialize(self, cam):
-        """camera::initialize on the public fields -> (15 doubles incl. background, image_height, sqrt_spp)"""
-        pub = np.array([*cam.lookfrom, *cam.lookat, *cam.vup, cam.vfov, cam.aspect_ratio, cam.focus_dist], dtype=np.float64)
-        out = np.zeros(12)
+        """camera::initialize on the public fields -> (22 doubles: center pixel00 du dv background disk_u disk_v
+        defocus_angle, image_height, sqrt_spp)"""
+        pub = np.array([*cam.lookfrom, *cam.lookat, *cam.vup, cam.vfov, cam.aspect_ratio, cam.focus_dist,
+                        cam.defocus_angle], dtype=np.float64)
+        out = np.zeros(19)
         h, s = C.c_int32(0), C.c_int32(0)
         self.lib.oracle_camera_initialize(pub, cam.image_width, cam.samples_per_pixel, out, C.byref(h), C.byref(s))
-        return np.concatenate([out, np.array(cam.background, dtype=np.float64)]), h.value, s.value
+        return np.concatenate([out[:12], np.array(cam.background, dtype=np.float64), out[12:19]]), h.value, s.value
 
     def colors_to_rgb8(self, fb, spp):
         fb = np.ascontiguousarray(fb, dtype=np.float64)

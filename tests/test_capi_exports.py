@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
 def test_struct_layouts_match_the_header():
     assert C.sizeof(capi.Material) == 48
     assert C.sizeof(capi.CameraPublic) == 16 * 8 + 16
-    assert C.sizeof(capi.CameraState) == 15 * 8 + 16
+    assert C.sizeof(capi.CameraState) == 15 * 8 + 16 + 7 * 8
     assert C.sizeof(capi.RenderParams) == 8 + 8 * 4
     assert C.sizeof(capi.Stats) == 88
     assert C.sizeof(capi.SceneInfo) == 32
@@ -58,10 +58,14 @@ def test_camera_initialize_rejects_bad_input(scenes):
     cam.image_width = 0
     with pytest.raises(capi.BdptError):
         capi.camera_initialize(cam)
-    cam.image_width = 8
-    cam.defocus_angle = 1.0
-    with pytest.raises(capi.BdptError, match="defocus"):
-        capi.camera_initialize(cam)
+
+
+def test_camera_initialize_defocus_disk_matches_oracle(scenes, oracle):
+    flat = scenes.showcase_with_defocus(32, 16, 6)
+    st = capi.camera_initialize(flat.camera)
+    cam22, H, sqrt_spp = oracle.camera_initialize(flat.camera)
+    assert st.defocus_angle == 4.0 and any(st.defocus_disk_u) and any(st.defocus_disk_v)
+    assert np.array_equal(st.as_array().view(np.uint64), cam22.view(np.uint64))
 
 
 def test_sqrt_spp_truncation(scenes):

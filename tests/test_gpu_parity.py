@@ -44,6 +44,7 @@ CASES = {
     "cornell_d2": lambda s: s.cornell_box(16, 5, 2),
     "cornell_d12": lambda s: s.cornell_box(16, 2, 12),
     "showcase_d20": lambda s: s.materials_showcase(24, 4, 20),
+    "showcase_defocus": lambda s: s.showcase_with_defocus(32, 16, 6),
 }
 
 

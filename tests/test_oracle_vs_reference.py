@@ -30,6 +30,7 @@ CASES = {
     "cornell_d2": lambda s: s.cornell_box(16, 5, 2),
     "cornell_d12": lambda s: s.cornell_box(16, 2, 12),
     "showcase_d20": lambda s: s.materials_showcase(24, 4, 20),
+    "showcase_defocus": lambda s: s.showcase_with_defocus(32, 16, 6),
 }
 
 
@@ -46,6 +47,8 @@ def test_camera_initialize(case, oracle):
     cam15, H, sqrt_spp = oracle.camera_initialize(flat.camera)
     assert_bit_equal(cam15[:12], g["camera"][:12], "camera::initialize")
     assert H == int(g["camera"][12]) and sqrt_spp == int(g["camera"][13])
+    if len(g["camera"]) >= 20:      # fixtures made since the defocus disk is exported
+        assert_bit_equal(cam15[15:21], g["camera"][14:20], "defocus disk")
 
 
 def test_triangle_precompute(case):
