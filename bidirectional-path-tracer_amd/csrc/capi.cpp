@@ -270,7 +270,9 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     per_cu = env_int("BDPT_WF_BLOCKS_PER_CU", per_cu);
     cfg.persistent_blocks = ctx->cu_count * per_cu;
     cfg.refill_threshold = env_int("BDPT_WF_REFILL", 16);
-    cfg.leaf_threshold = env_int("BDPT_WF_LEAF", 24);
+    cfg.leaf_threshold = env_int("BDPT_WF_LEAF", 32);
+    cfg.leaf_inner = env_int("BDPT_WF_LEAF_INNER", cfg.leaf_threshold > 1 ? cfg.leaf_threshold / 2 : 1);
+    if (cfg.leaf_inner < 1) cfg.leaf_inner = 1;
     cfg.chunk = (uint32_t)env_int("BDPT_WF_CHUNK", 512);   // measured: the cursor is one address, and its atomics cost more than a coarser split
     cfg.stream_blocks = ctx->cu_count * 8;
 

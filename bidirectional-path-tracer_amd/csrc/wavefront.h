@@ -55,6 +55,7 @@ struct WfLaunchCfg {
     size_t lds_bytes;
     int refill_threshold;     // a wave fetches new rays when at least this many of its lanes are idle
     int leaf_threshold;       // lanes of a wave that must stand at a leaf before the wave turns to triangle tests
+    int leaf_inner;           // ... and it stays with the triangles of those leaves while this many lanes have one left
     uint32_t chunk;           // ray indices a wave takes from the global cursor at a time
     uint32_t top_nodes;       // 128-byte records of the top tree levels each such workgroup keeps in LDS
     int lds_stack;            // traversal stack entries per lane kept in LDS (the rest of the stack is scratch)

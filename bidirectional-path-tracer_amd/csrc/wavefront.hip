@@ -272,7 +272,7 @@ BDPT_DEV bool reference_reaches(const SceneDev& sc, uint32_t node, V3 o, V3 d, d
 template <bool SHADOW, bool STATS, class Mem>
 BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, uint32_t count,
                              uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk,
-                             const int kLeafThreshold, const double coord_bound, double* lds_stack, const int kLdsStack,
+                             const int kLeafThreshold, const int kLeafInner, const double coord_bound, double* lds_stack, const int kLdsStack,
                              const uint32_t first_base) {
     const float bound_f32 = float_up(coord_bound);
     bool has = false;
@@ -397,7 +397,8 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                 }
             }
         } else {
-            if (has && leaf_left > 0) {
+          for (;;) {
+            if (has && leaf_left > 0 && !done) {
                 const GpuTri tr = mem.stri(leaf_next);
                 leaf_next++;
                 leaf_left--;
@@ -422,6 +423,9 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                 }
                 if (leaf_left == 0 && !done) pop = true;
             }
+            // go on with the next triangles of the same leaves while enough lanes have one
+            if (__builtin_popcountll(__ballot(has && leaf_left > 0 && !done)) < kLeafInner) break;
+          }
         }
         if (pop) {
             done = true;
@@ -491,7 +495,8 @@ template <bool SHADOW, bool STATS, bool LDS_SCENE>
 __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
                                                     const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                     unsigned long long* stats, int refill_threshold, uint32_t chunk,
-                                                    uint32_t top_nodes, int leaf_threshold, uint32_t scene_lds_bytes, int lds_stack) {
+                                                    uint32_t top_nodes, int leaf_threshold, int leaf_inner, uint32_t scene_lds_bytes,
+                                                    int lds_stack) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
     double* const l_stack = reinterpret_cast<double*>(smem + scene_lds_bytes);     // [lds_stack + 1][kBlock]
@@ -520,13 +525,13 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
             GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
             stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
             TreeMem<GpuQuadNode> mem{l_nodes, l_tris};
-            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, sc.coord_bound, l_stack, lds_stack, first_base);
+            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
         } else {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
             stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
             TopLdsMem<GpuQuadNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
-            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, sc.coord_bound, l_stack, lds_stack, first_base);
+            traverse_queue<SHADOW, STATS>(mem, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
         }
     }
 }
@@ -882,7 +887,7 @@ static void launch_traverse_as(const SceneDev& sc, const WfBuffers& wb, const ui
                                hipStream_t st) {
     hipLaunchKernelGGL((k_traverse<SHADOW, STATS, LDS_SCENE>), dim3(cfg.persistent_blocks), dim3(kBlock), traverse_lds_bytes(cfg), st,
                        sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.top_nodes,
-                       cfg.leaf_threshold, (uint32_t)scene_lds_bytes(cfg), cfg.lds_stack);
+                       cfg.leaf_threshold, cfg.leaf_inner, (uint32_t)scene_lds_bytes(cfg), cfg.lds_stack);
 }
 
 template <bool SHADOW>
