@@ -190,7 +190,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     if (n_owned >= ((int64_t)1 << 31)) return fail(BDPT_ERR_UNSUPPORTED, "more than 2^31 pixels in one call");
     // bytes of state per sample slot
-    const size_t per_slot = sizeof(double) * (6 + 3 + 3 + 3) + sizeof(uint32_t) * 6 + vslots * 10 * sizeof(double) +
+    const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 6 + vslots * 10 * sizeof(double) +
                             vis_words * sizeof(unsigned long long) + shadow_per_slot * 8 * sizeof(double);
     // Wavefront state of all batches in flight.  Large batches mean few, long launches (a frame is tens of thousands
     // of them), so the state takes most of what the device has free: up to kWfWorkspaceBudget of the 288 GB.
@@ -222,7 +222,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     // carve one workspace per stream
     size_t off = 0;
     auto take = [&off](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
-    const size_t o_ray = take(ns * 6 * 8), o_thr = take(ns * 3 * 8), o_hit = take(ns * 3 * 8), o_res = take(ns * 3 * 8);
+    const size_t o_ray = take(ns * 6 * 8), o_thr = take(ns * 3 * 8), o_hit = take(ns * 8), o_res = take(ns * 3 * 8);
     const size_t o_tri = take(ns * 4), o_ctr = take(ns * 4), o_cnt = take(ns * 4);
     const size_t o_q0 = take(ns * 4), o_q1 = take(ns * 4), o_cq = take(ns * 4);
     const size_t o_vtx = take(ns * vslots * 10 * 8), o_vis = take(ns * vis_words * 8), o_sh = take(shadow_cap * 8 * 8);

@@ -16,7 +16,7 @@ namespace bdpt {
 struct WfBuffers {
     double* ray;          // [6][ns]  origin, direction of the ray to trace next
     double* thr;          // [3][ns]  path throughput
-    double* hit;          // [3][ns]  t, u, v of the last closest hit
+    double* hit;          // [ns]     t of the last closest hit
     int32_t* hit_tri;     // [ns]     triangle id or -1
     uint32_t* ctr;        // [ns]     random numbers drawn so far by the sample
     double* result;       // [3][ns]  radiance of the sample

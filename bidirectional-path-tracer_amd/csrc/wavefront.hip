@@ -418,7 +418,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                     // equal t: the reference keeps the triangle it visits later = larger position in
                     // its leaf order (tr.pad)
                     else if (t < closest || best_pos < 0 || tr.pad > best_pos) {
-                        closest = t; h.t = t; h.u = u; h.v = v; best_pos = tr.pad; h.tri = tr.pad;
+                        closest = t; h.t = t; best_pos = tr.pad; h.tri = tr.pad;
                     }
                 }
                 if (leaf_left == 0 && !done) pop = true;
@@ -451,9 +451,10 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                     atomicOr(&wb.vis[(uint64_t)(bidx >> 6) * wb.ns + s], 1ull << (bidx & 63u));
                 }
             } else {
-                const uint64_t ns = wb.ns;
                 wb.hit_tri[slot] = (h.tri >= 0) ? sc.stris[h.tri].pad : -1;      // leaf position -> triangle id
-                if (h.tri >= 0) { wb.hit[slot] = h.t; wb.hit[ns + slot] = h.u; wb.hit[2 * ns + slot] = h.v; }
+                // the barycentric coordinates of the hit are not kept: nothing on this path reads them (the
+                // reference's hit_record carries u, v for textures, and every texture here is a solid colour)
+                if (h.tri >= 0) wb.hit[slot] = h.t;
             }
             has = false;
         }
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
             V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
             HitLite h;
-            h.tri = tri; h.t = wb.hit[slot]; h.u = wb.hit[ns + slot]; h.v = wb.hit[2 * ns + slot];
+            h.tri = tri; h.t = wb.hit[slot]; h.u = 0; h.v = 0;
             const uint32_t ctr0 = wb.ctr[slot];
             Rng rng = slot_rng(cam, b, slot, ctr0);
             Bounce bo;
