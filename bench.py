@@ -36,12 +36,12 @@ PKG = "bidirectional-path-tracer_amd"
 HBM_PEAK_GBS = 8000.0
 
 # Algorithmic bytes (FP64 records of the device layout), see DESIGN.md "Algorithmic bytes":
-#   closest-hit ray : origin + direction 48, queue index 4, triangle id 4, (t, u, v) 24
+#   closest-hit ray : origin + direction 48, queue index 4, triangle id 4, t 8
 #   visibility ray  : origin + direction + max_t + tag 64, visibility word 8
 #   node record     : counted by the kernels in units of 64 bytes; triangle 80; stored path vertex 80
-#   per ray outside traversal (shading): ray + hit 76 in, next ray + throughput 72 out
+#   per ray outside traversal (shading): ray + hit 60 in, next ray + throughput 72 out
 #   per connection pair: both vertices read when its ray is generated and when it is accumulated
-B_RAY_CLOSEST, B_RAY_SHADOW, B_NODE, B_TRI, B_VERTEX, B_PIXEL, B_RAY_STATE = 80, 72, 64, 80, 80, 24, 148
+B_RAY_CLOSEST, B_RAY_SHADOW, B_NODE, B_TRI, B_VERTEX, B_PIXEL, B_RAY_STATE = 64, 72, 64, 80, 80, 24, 132
 
 WORKLOADS = {
     # name: (builder, kwargs, description)
