@@ -35,7 +35,7 @@ PKG = "bidirectional-path-tracer_amd"
 
 HBM_PEAK_GBS = 8000.0
 
-# Algorithmic bytes (FP64 records of the device layout), see DESIGN.md "Algorithmic bytes":
+# Algorithmic bytes (FP64 records of the device layout):
 #   closest-hit ray : origin + direction 48, queue index 4, triangle id 4, t 8
 #   visibility ray  : origin + direction + max_t + tag 64, visibility word 8
 #   node record     : counted by the kernels in units of 64 bytes; triangle 80; stored path vertex 80
