@@ -17,7 +17,7 @@ struct WfBuffers {
     double* ray;          // [6][ns]  origin, direction of the ray to trace next
     double* thr;          // [3][ns]  path throughput
     double* hit;          // [ns]     t of the last closest hit
-    int32_t* hit_tri;     // [ns]     triangle id or -1
+    int32_t* hit_tri;     // [ns]     position of the hit triangle in the leaf-ordered table, or -1
     uint32_t* ctr;        // [ns]     random numbers drawn so far by the sample
     double* result;       // [3][ns]  radiance of the sample
     uint32_t* counts;     // [ns]     n_eye | n_light << 12 | flags << 24

@@ -451,7 +451,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                     atomicOr(&wb.vis[(uint64_t)(bidx >> 6) * wb.ns + s], 1ull << (bidx & 63u));
                 }
             } else {
-                wb.hit_tri[slot] = (h.tri >= 0) ? sc.stris[h.tri].pad : -1;      // leaf position -> triangle id
+                wb.hit_tri[slot] = h.tri;      // position in the reference's leaf order (k_shade turns it into the triangle id)
                 // the barycentric coordinates of the hit are not kept: nothing on this path reads them (the
                 // reference's hit_record carries u, v for textures, and every texture here is a solid colour)
                 if (h.tri >= 0) wb.hit[slot] = h.t;
@@ -562,7 +562,8 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             slots[j] = slot;
             int pi, pj, ps;
             if (!slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
-            const int32_t tri = wb.hit_tri[slot];
+            const int32_t pos = wb.hit_tri[slot];
+            const int32_t tri = pos < 0 ? -1 : sc.stris[pos].pad;      // leaf position -> triangle id
             V3 T = mk(wb.thr[slot], wb.thr[ns + slot], wb.thr[2 * ns + slot]);
             if (tri < 0) {
                 if (EYE) {   // camera.h:337-338: background_contrib (0) += throughput * background
