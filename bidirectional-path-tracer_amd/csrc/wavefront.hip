@@ -296,7 +296,6 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
     RayF32 rf = {};
     HitLite h;
     h.t = 0; h.u = 0; h.v = 0; h.tri = -1;
-    int32_t best_pos = -1;
     // first_base: the wave's first chunk, taken from the cursor by its workgroup for all its waves at once (all
     // waves start at the same moment: one atomic per wave on one address would queue up)
     uint32_t pool_next = 0, pool_end = 0;     // wave-uniform
@@ -344,7 +343,6 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                         leaf_left = 0;
                         sp = 0;
                         h.tri = -1;
-                        best_pos = -1;
                         has = true;
                         if (STATS) n_rays++;
                     }
@@ -417,8 +415,8 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                     }
                     // equal t: the reference keeps the triangle it visits later = larger position in
                     // its leaf order (tr.pad)
-                    else if (t < closest || best_pos < 0 || tr.pad > best_pos) {
-                        closest = t; h.t = t; best_pos = tr.pad; h.tri = tr.pad;
+                    else if (t < closest || h.tri < 0 || tr.pad > h.tri) {
+                        closest = t; h.tri = tr.pad;           // the hit distance IS the running bound
                     }
                 }
                 if (leaf_left == 0 && !done) pop = true;
@@ -454,7 +452,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                 wb.hit_tri[slot] = h.tri;      // position in the reference's leaf order (k_shade turns it into the triangle id)
                 // the barycentric coordinates of the hit are not kept: nothing on this path reads them (the
                 // reference's hit_record carries u, v for textures, and every texture here is a solid colour)
-                if (h.tri >= 0) wb.hit[slot] = h.t;
+                if (h.tri >= 0) wb.hit[slot] = closest;
             }
             has = false;
         }
