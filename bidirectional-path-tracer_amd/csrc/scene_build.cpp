@@ -343,6 +343,7 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
         }
         t.material = tri_material[i];
         t.pad = 0;
+        if (materials[tri_material[i]].type == BDPT_LAMBERTIAN) out.has_lambertian = true;
         const double nx = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1];
         const double ny = t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2];
         const double nz = t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0];

@@ -22,6 +22,7 @@ struct HostScene {
     std::vector<GpuTri> xtris;           // its triangles in leaf order (pad = position in stris)
     double coord_bound = 0.0;            // largest |coordinate| of its boxes
     uint32_t sah_stack = 0;              // most entries its traversal stack can hold at once
+    bool has_lambertian = false;         // some triangle has a lambertian material (the only connectable kind of vertex)
     std::vector<GpuTriAux> aux;
     std::vector<GpuMaterial> mats;
     std::vector<uint32_t> light_tris;

@@ -68,7 +68,8 @@ hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* qu
                      uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
                     const uint32_t* queue_in, const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
-                    uint32_t* count_out, bool last_bounce, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
+                    uint32_t* count_out, bool last_bounce, bool store_vertices, const WfLaunchCfg& cfg, unsigned long long* stats,
+                    hipStream_t st);
 hipError_t wf_gen_light(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* queue_out,
                         uint32_t* count_out, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
 hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* conn_count,

@@ -539,7 +539,7 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
 template <bool EYE, bool STATS>
 __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
                                                   const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
-                                                  uint32_t* count_out, int last_bounce, unsigned long long* stats) {
+                                                  uint32_t* count_out, int last_bounce, int store_vertices, unsigned long long* stats) {
     __shared__ uint32_t s_wave[kStageWaves];
     __shared__ uint32_t s_base;
     const uint32_t count = count_in_ptr ? *count_in_ptr : count_in_imm;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             shade_bounce<EYE>(sc, o, d, h, T, rng, bo);
             // state that a bounce leaves as it was is not written again (a specular bounce keeps no vertex, a
             // dielectric one leaves the throughput alone: x * 1.0 is x)
-            if (bo.keep) {
+            if (bo.keep && store_vertices) {       // (no vertex store in a scene that cannot form a connection)
                 uint32_t cnt = wb.counts[slot];
                 const uint32_t ne = cnt & 0xFFFu, nl = (cnt >> 12) & 0xFFFu;
                 slot_store(wb, slot).put(EYE ? (int)ne : depth + (int)nl, bo.vx);
@@ -916,15 +916,16 @@ hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* s
 
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
                     const uint32_t* queue_in, const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
-                    uint32_t* count_out, bool last_bounce, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
+                    uint32_t* count_out, bool last_bounce, bool store_vertices, const WfLaunchCfg& cfg, unsigned long long* stats,
+                    hipStream_t st) {
     dim3 grid(cfg.stream_blocks), block(kStageBlock);
-    const int last = last_bounce ? 1 : 0;
+    const int last = last_bounce ? 1 : 0, keep = store_vertices ? 1 : 0;
     if (eye) {
-        if (stats) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, stats);
-        else hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, stats);
+        if (stats) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        else hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
     } else {
-        if (stats) hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, stats);
-        else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, stats);
+        if (stats) hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
     }
     return hipGetLastError();
 }
