@@ -269,6 +269,37 @@ def test_one_triangle_and_one_light(scenes, ctx, oracle):
         sc.close()
 
 
+def test_scene_without_lambertian_surfaces(scenes, ctx, oracle):
+    """No lambertian triangle -> no vertex can ever be connected: the pipeline leaves out light subpaths and
+    connections (and their storage) for the whole scene.  Same bits as the oracle, as the single-kernel path and as
+    the counting modes."""
+    flat = scenes.FlatScene()
+    light = flat.add_material(scenes.Material(scenes.DIFFUSE_LIGHT, (6, 5, 4)))
+    mirror = flat.add_material(scenes.Material(scenes.METAL, (.8, .8, .9), fuzz=0.05))
+    glass = flat.add_material(scenes.Material(scenes.DIELECTRIC, ior=1.5))
+    scenes.add_quad_triangles(flat, (-2, 4, -2), (4, 0, 0), (0, 0, 4), light)
+    scenes.add_quad_triangles(flat, (-6, 0, -6), (12, 0, 0), (0, 0, 12), mirror)
+    scenes.add_box_triangles(flat, (-1, 0.2, -1), (1, 2.2, 1), glass, 20.0)
+    scenes.add_uv_sphere(flat, (2.5, 1.0, 0.5), 1.0, glass, 8, 16)
+    flat.camera = scenes.Camera(aspect_ratio=1.5, image_width=36, samples_per_pixel=16, max_depth=8,
+                                background=(0.05, 0.1, 0.2), vfov=45, lookfrom=(0, 3, -9), lookat=(0, 1, 0), vup=(0, 1, 0))
+    sc = ctx.scene(flat)
+    cam = capi.camera_initialize(flat.camera)
+    fb = sc.render(cam, seed=17)
+    ofb, ostats, _ = oracle.scene(flat).render(cam.as_array(), 36, cam.sqrt_spp, 8, 17, (0, 0, 36, cam.image_height))
+    assert fb.max() > 0
+    assert_bit_equal(fb, ofb, "no lambertian surface, wavefront")
+    assert_bit_equal(sc.render(cam, seed=17, megakernel=True), ofb, "no lambertian surface, single kernel")
+    fb2, st = sc.render(cam, seed=17, want_stats="work")
+    assert_bit_equal(fb2, ofb, "no lambertian surface, counting mode")
+    # the pipeline's own work counters: no light subpath was sampled, so fewer draws than the reference makes
+    assert 0 < st.rng_draws < int(ostats[7]) and st.connection_pairs == 0 and st.shadow_rays == 0
+    fb3, ref_st = sc.render(cam, seed=17, want_stats=True)          # reference-equivalent counters (single-kernel path)
+    assert_bit_equal(fb3, ofb, "no lambertian surface, reference counters")
+    assert ref_st.rng_draws == int(ostats[7]) and ref_st.rays_traced == int(ostats[0])
+    sc.close()
+
+
 def test_large_scene_uses_global_memory_path(scenes, ctx, oracle):
     """More nodes + triangles than the LDS staging limit: the traversal reads the tables from
     global memory; results are still the oracle's."""
