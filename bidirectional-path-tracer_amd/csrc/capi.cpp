@@ -212,7 +212,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     int want_streams = env_int("BDPT_WF_STREAMS", 4);
     want_streams = want_streams < 1 ? 1 : (want_streams > kWfStreams ? kWfStreams : want_streams);
     int64_t ns_target = (int64_t)(budget / want_streams / per_slot);
-    const int64_t ns_cap = (int64_t)1 << env_int("BDPT_WF_BATCH_LOG2", 24);
+    const int64_t ns_cap = (int64_t)1 << env_int("BDPT_WF_BATCH_LOG2", 26);
     if (ns_target > ns_cap) ns_target = ns_cap;
     if (spp > ns_target) return fail(BDPT_ERR_UNSUPPORTED, "samples per pixel exceed the wavefront batch capacity");
     int64_t pixels_per_batch = ns_target / spp;
