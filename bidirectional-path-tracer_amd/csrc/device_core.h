@@ -301,7 +301,8 @@ struct Bounce {
     V3 o, d, T;
 };
 
-template <bool EYE>
+// LAMBERT = false: for scenes without a lambertian triangle (that material's code is the largest part of the function)
+template <bool EYE, bool LAMBERT = true>
 BDPT_DEV void shade_bounce(const SceneDev& sc, V3 o, V3 d, const HitLite& h, V3 throughput, Rng& rng, Bounce& out) {
     const GpuTriAux ax = sc.aux[h.tri];
     const int32_t mat_id = sc.tris[h.tri].material;
@@ -350,6 +351,7 @@ BDPT_DEV void shade_bounce(const SceneDev& sc, V3 o, V3 d, const HitLite& h, V3 
         out.cont = true;
         return;
     }
+    if (!LAMBERT) return;
     // lambertian, material.h:47-58 + pdf.h:32-47 + camera.h:361-368
     V3 w;
     V3 scattered = onb_transform(normal, random_cosine_direction(rng), w);

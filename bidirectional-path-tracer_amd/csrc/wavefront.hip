@@ -536,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
 }
 
 // ------------------------------------------------------------------ shading of one bounce
-template <bool EYE, bool STATS>
+template <bool EYE, bool STATS, bool LAMBERT>
 __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
                                                   const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
                                                   uint32_t* count_out, int last_bounce, int store_vertices, unsigned long long* stats) {
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             const uint32_t ctr0 = wb.ctr[slot];
             Rng rng = slot_rng(cam, b, slot, ctr0);
             Bounce bo;
-            shade_bounce<EYE>(sc, o, d, h, T, rng, bo);
+            shade_bounce<EYE, LAMBERT>(sc, o, d, h, T, rng, bo);
             // state that a bounce leaves as it was is not written again (a specular bounce keeps no vertex, a
             // dielectric one leaves the throughput alone: x * 1.0 is x)
             if (bo.keep && store_vertices) {       // (no vertex store in a scene that cannot form a connection)
@@ -921,11 +921,13 @@ hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& w
     dim3 grid(cfg.stream_blocks), block(kStageBlock);
     const int last = last_bounce ? 1 : 0, keep = store_vertices ? 1 : 0;
     if (eye) {
-        if (stats) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
-        else hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        if (stats) hipLaunchKernelGGL((k_shade<true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        else if (store_vertices) hipLaunchKernelGGL((k_shade<true, false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        // no vertex is stored <=> the scene has no lambertian triangle: the variant without that material's code
+        else hipLaunchKernelGGL((k_shade<true, false, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
     } else {
-        if (stats) hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
-        else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        if (stats) hipLaunchKernelGGL((k_shade<false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        else hipLaunchKernelGGL((k_shade<false, false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
     }
     return hipGetLastError();
 }
