@@ -282,10 +282,10 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     if (cfg.lds_stack > kQuadStackEntries) cfg.lds_stack = kQuadStackEntries;
     int per_cu = 1;
     HIP_TRY(wf_prepare_traverse(cfg, &per_cu));
-    if (!cfg.lds_scene && per_cu > 4) per_cu = 4;   // measured: more resident waves only thrash L1 on large scenes
-    // A scene without lambertian triangles runs the smaller shading kernel (112 registers): beside THREE traversal
-    // workgroups (3 x 88 registers per SIMD lane) two of its waves fit a SIMD instead of one (measured +1.4 %).
-    if (!connections && per_cu > 3) per_cu = 3;
+    // Three traversal workgroups per CU (3 x 88 registers per SIMD lane) leave room for TWO waves of a shading kernel
+    // (<= 120 registers) on every SIMD; with four, one fits.  More resident traversal waves only thrash L1 on large
+    // scenes anyway.  Measured: 3 beats 4 by about 1 % on every workload.
+    if (per_cu > 3) per_cu = 3;
     per_cu = env_int("BDPT_WF_BLOCKS_PER_CU", per_cu);
     cfg.persistent_blocks = ctx->cu_count * per_cu;
     cfg.refill_threshold = env_int("BDPT_WF_REFILL", 16);

@@ -548,12 +548,11 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
     uint32_t n_stored = 0;
     // whole workgroups iterate together so that the append sees every thread
     for (uint32_t tile = blockIdx.x * kStageTile; tile < count; tile += gridDim.x * kStageTile) {
-        bool cont[kStagePerThread];
+        uint32_t cont_mask = 0;          // bit j: entry j goes on (one register instead of four while the entries are shaded)
         uint32_t slots[kStagePerThread];
 #pragma unroll 1
         for (int j = 0; j < kStagePerThread; j++) {
             const uint32_t k = tile + (uint32_t)j * kStageBlock + threadIdx.x;
-            cont[j] = false;
             slots[j] = 0;
             if (k >= count) continue;
             const uint32_t slot = queue_in ? queue_in[k] : k;
@@ -595,7 +594,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             }
             if (rng.counter != ctr0) wb.ctr[slot] = rng.counter;
             if (bo.cont && !last_bounce) {
-                cont[j] = true;
+                cont_mask |= 1u << j;
                 wb.ray[slot] = bo.o.x; wb.ray[ns + slot] = bo.o.y; wb.ray[2 * ns + slot] = bo.o.z;
                 wb.ray[3 * ns + slot] = bo.d.x; wb.ray[4 * ns + slot] = bo.d.y; wb.ray[5 * ns + slot] = bo.d.z;
                 const bool same_bits = __double_as_longlong(bo.T.x) == __double_as_longlong(T.x) &&
@@ -606,6 +605,9 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
                 }
             }
         }
+        bool cont[kStagePerThread];
+#pragma unroll
+        for (int j = 0; j < kStagePerThread; j++) cont[j] = (cont_mask >> j) & 1u;
         tile_append(cont, slots, queue_out, count_out, s_wave, &s_base);
     }
     if (STATS) flush_wave_counter(&stats[10], n_stored);
