@@ -252,7 +252,7 @@ BDPT_DEV void sort2(double& a, double& b) {
 }
 
 // aabb::hit (aabb.h:41-66) of every bvh_node from `node` up to the root, with the interval [0.001, max_t]
-BDPT_DEV bool reference_reaches(const SceneDev& sc, uint32_t node, V3 o, V3 d, double max_t) {
+__device__ __attribute__((noinline)) bool reference_reaches(const SceneDev& sc, uint32_t node, V3 o, V3 d, double max_t) {
     const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;       // aabb.h:48
     for (uint32_t n = node; n != kEndOfTree; n = sc.node_parent[n]) {
         const GpuNode nd = sc.nodes[n];
