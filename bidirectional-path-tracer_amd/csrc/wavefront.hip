@@ -143,6 +143,7 @@ constexpr int32_t kPop = (int32_t)0x80000000;   // neither an interior index (>=
 
 template <class NodeT>
 struct TreeMem {
+    static constexpr bool kKeepTag = true;     // (see traverse_queue: registers are not the limit of this variant)
     const NodeT* wn;          // global or LDS copy
     const GpuTri* st;
     BDPT_DEV NodeT wnode(int32_t i) const { return wn[i]; }
@@ -152,6 +153,7 @@ struct TreeMem {
 // Large scenes: the records nearest the root come from LDS, the deeper ones from global memory.
 template <class NodeT>
 struct TopLdsMem {
+    static constexpr bool kKeepTag = false;
     const NodeT* lds;         // first n_lds records
     const NodeT* wn;
     const GpuTri* st;
@@ -290,6 +292,11 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
         else stk_quad[sp - kLdsStack] = e;
         sp++;
     };
+    // visibility rays: the pair a ray belongs to.  The variant that walks records in global memory keeps only the queue
+    // entry and reads the tag again when the ray is done: one register less, which is what lets two waves of a shading
+    // kernel fit beside three workgroups of it; the variant with the whole scene in LDS has that register to spare and
+    // is spared the extra load on its exit path.
+    uint32_t entry = 0;
     unsigned long long tag = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     double closest = 0;
@@ -328,7 +335,8 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                         o = mk(wb.shadow[k], wb.shadow[cap + k], wb.shadow[2 * cap + k]);
                         d = mk(wb.shadow[3 * cap + k], wb.shadow[4 * cap + k], wb.shadow[5 * cap + k]);
                         tmax0 = wb.shadow[6 * cap + k];
-                        tag = (unsigned long long)__double_as_longlong(wb.shadow[7 * cap + k]);
+                        if (Mem::kKeepTag) tag = (unsigned long long)__double_as_longlong(wb.shadow[7 * cap + k]);
+                        else entry = k;
                     } else {
                         slot = queue ? queue[k] : k;
                         const uint64_t ns = wb.ns;
@@ -444,6 +452,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
         if (done) {
             if (SHADOW) {
                 if (h.tri < 0) {       // nothing in the way: the pair is visible
+                    if (!Mem::kKeepTag) tag = (unsigned long long)__double_as_longlong(wb.shadow[7 * wb.shadow_cap + entry]);
                     const uint32_t s = (uint32_t)(tag >> 16);
                     const uint32_t bidx = (uint32_t)(tag & 0xFFFFu);
                     atomicOr(&wb.vis[(uint64_t)(bidx >> 6) * wb.ns + s], 1ull << (bidx & 63u));
