@@ -210,6 +210,8 @@ def main():
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     ctx = capi.Context(local_rank)
+    # the frames here are large: let the per-sample state of the batches in flight take most of the 288 GB
+    ctx.set_workspace_limit(int(os.environ.get("BDPT_BENCH_WORKSPACE_GB", "176")) << 30)
     scene = ctx.scene(flat)
     cam = capi.camera_initialize(flat.camera)
     W, H, spp_used, depth = cam.image_width, cam.image_height, cam.sqrt_spp ** 2, cam.max_depth

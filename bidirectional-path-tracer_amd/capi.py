@@ -84,8 +84,11 @@ EXPORTED_SYMBOLS = [
     "bdpt_render_get_kernel_ms", "bdpt_render_get_stage_ms",
     "bdpt_colors_to_rgb8", "bdpt_colors_to_rgb8_device", "bdpt_device_sincos", "bdpt_device_random_doubles",
     "bdpt_device_arith", "bdpt_scene_file_load", "bdpt_scene_file_destroy", "bdpt_scene_file_get", "bdpt_write_png", "bdpt_debug_yaml_to_json",
-    "bdpt_reduce_framebuffer",
+    "bdpt_reduce_framebuffer", "bdpt_context_set_workspace_limit", "bdpt_context_set_query_walker",
 ]
+
+WALKER_PIPELINE = 0          # traversal kernels of the render pipeline (default)
+WALKER_REFERENCE_TREE = 1    # stackless walk over the reference's own tree (verification)
 
 _lib = None
 
@@ -135,6 +138,8 @@ def load_library() -> C.CDLL:
     lib.bdpt_write_png.argtypes = [C.c_char_p, vp, C.c_int32, C.c_int32]
     lib.bdpt_reduce_framebuffer.argtypes = [vp, vp, C.c_uint64, vp]
     lib.bdpt_debug_yaml_to_json.argtypes = [C.c_char_p, C.c_char_p, u64]
+    lib.bdpt_context_set_workspace_limit.argtypes = [vp, u64]
+    lib.bdpt_context_set_query_walker.argtypes = [vp, C.c_int]
     for name in EXPORTED_SYMBOLS:
         if name != "bdpt_last_error":
             getattr(lib, name).restype = C.c_int
@@ -240,6 +245,14 @@ class Context:
 
     def __del__(self):
         self.close()
+
+    def set_workspace_limit(self, n_bytes: int) -> None:
+        """Most device memory the context may take for the per-sample state of a render (0: the default)."""
+        _check(self.lib.bdpt_context_set_workspace_limit(self.h, int(n_bytes)))
+
+    def set_query_walker(self, walker: int) -> None:
+        """WALKER_PIPELINE / WALKER_REFERENCE_TREE for trace_closest (without counters) and visible."""
+        _check(self.lib.bdpt_context_set_query_walker(self.h, int(walker)))
 
     # -- test hooks ---------------------------------------------------------------
     def device_sincos(self, x):

@@ -87,7 +87,8 @@ struct SceneDev {
     const GpuTri* stris;            // triangles in leaf order; `pad` holds the original triangle id
     const uint32_t* sleaf;          // per entry of `stris`: the node of `nodes` that holds the triangle
     const GpuQuadNode* xnodes;      // closest-hit hierarchy (surface-area heuristic, four children, FP32 boxes)
-    const GpuTri* xtris;            // its triangles in its own leaf order; `pad` = position in `stris`
+    const GpuTri* xtris;            // its triangles in its own leaf order; `pad` = position in `stris`; `material` holds
+                                    // the bits of an FP32 number instead: the triangle's grazing threshold (wavefront.hip)
     uint32_t n_xnodes;
     const GpuTriAux* aux;
     const GpuMaterial* mats;
@@ -95,6 +96,7 @@ struct SceneDev {
     const double* light_accum;      // running sums of the areas exactly as triangle.h:212-219 accumulates them
     double light_total_area;
     double coord_bound;             // largest |coordinate| of any box of the closest-hit hierarchy
+    double bary_margin;             // a hit closer than this (in barycentric units) to its triangle's outline is re-checked
     uint32_t n_nodes, n_tris, n_mats, n_lights;
 };
 

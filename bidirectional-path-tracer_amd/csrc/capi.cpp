@@ -42,19 +42,57 @@ int hip_fail(hipError_t e, const char* what) {
 constexpr int kBlock = 256;
 constexpr int kStatWords = 11;
 constexpr int kWfStreams = 8;                               // most batches in flight (one HIP stream each)
-constexpr size_t kWfWorkspaceBudget = (size_t)176 << 30;     // bytes of wavefront state for all of them
 
-// tuning knobs, overridable from the environment for experiments
-int env_int(const char* name, int fallback) {
+// Tuning knobs, overridable from the environment for experiments.  Read once, when a context is created, and
+// clamped to what the kernels support.
+int env_int(const char* name, int fallback, int lo, int hi) {
     const char* v = std::getenv(name);
-    return (v && *v) ? std::atoi(v) : fallback;
+    int x = (v && *v) ? std::atoi(v) : fallback;
+    return x < lo ? lo : (x > hi ? hi : x);
 }
+
+struct Knobs {
+    int budget_gb;        // 0: the context's workspace limit decides
+    int streams;
+    int batch_log2;
+    int lds_kb;
+    int lds_stack;
+    int blocks_per_cu;    // 0: from the occupancy query, at most 3
+    int refill;
+    int leaf;
+    int leaf_inner;       // 0: half the leaf threshold
+    int chunk;
+};
+
+Knobs read_knobs() {
+    Knobs k;
+    k.budget_gb = env_int("BDPT_WF_BUDGET_GB", 0, 0, 224);
+    k.streams = env_int("BDPT_WF_STREAMS", 4, 1, kWfStreams);
+    k.batch_log2 = env_int("BDPT_WF_BATCH_LOG2", 26, 6, 30);
+    k.lds_kb = env_int("BDPT_WF_LDS_KB", 16, 1, 128);
+    k.lds_stack = env_int("BDPT_WF_LDS_STACK", 8, 0, kQuadStackEntries);
+    k.blocks_per_cu = env_int("BDPT_WF_BLOCKS_PER_CU", 0, 0, 16);
+    k.refill = env_int("BDPT_WF_REFILL", 16, 1, 64);         // above 64 no wave would ever fetch rays
+    k.leaf = env_int("BDPT_WF_LEAF", 32, 1, 64);
+    k.leaf_inner = env_int("BDPT_WF_LEAF_INNER", 0, 0, 64);
+    k.chunk = env_int("BDPT_WF_CHUNK", 512, 1, 1 << 20);
+    return k;
+}
+
+// Default limit of the library-managed render workspace; bdpt_context_set_workspace_limit raises or lowers it.
+constexpr size_t kDefaultWorkspaceLimit = (size_t)32 << 30;
 
 }  // namespace
 
 struct bdpt_context {
     int device = 0;
     int cu_count = 0;
+    Knobs knobs{};
+    size_t workspace_limit = 0;          // bytes; 0 = default (kDefaultWorkspaceLimit, at most a quarter of the free memory)
+    int query_walker = BDPT_WALKER_PIPELINE;
+    // workspace of the ray / visibility query entry points
+    void* query_ws = nullptr;
+    size_t query_ws_bytes = 0;
     // reusable device buffers
     double* vertex_ws = nullptr;
     size_t vertex_ws_bytes = 0;
@@ -121,6 +159,16 @@ int ensure_vertex_ws(bdpt_context* ctx, size_t bytes) {
     return BDPT_OK;
 }
 
+int ensure_query_ws(bdpt_context* ctx, size_t bytes) {
+    if (ctx->query_ws_bytes >= bytes) return BDPT_OK;
+    if (ctx->query_ws) (void)hipFree(ctx->query_ws);
+    ctx->query_ws = nullptr;
+    ctx->query_ws_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx->query_ws, bytes));
+    ctx->query_ws_bytes = bytes;
+    return BDPT_OK;
+}
+
 void read_stats(const unsigned long long* h, bdpt_stats* out) {
     out->rays_traced = h[0]; out->aabb_tests = h[1]; out->aabb_hits = h[2]; out->bvh_node_visits = h[3];
     out->triangle_tests = h[4]; out->triangle_hits = h[5]; out->shadow_rays = h[6]; out->connection_pairs = h[7];
@@ -141,8 +189,9 @@ GpuCamera to_gpu_camera(const bdpt_camera_state& c) {
 }
 
 // ---- single persistent kernel: one thread per sample does the whole of bidirectional_color
-int render_megakernel(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, uint64_t seed, int32_t n_rows,
-                      int x0, int x1, int64_t n_owned, double* d_fb, int stats_mode, bool unidirectional, hipStream_t stream) {
+int render_megakernel(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, uint64_t seed, const int32_t* rows,
+                      int32_t n_rows, int x0, int x1, int64_t n_owned, double* d_fb, int stats_mode, bool unidirectional,
+                      hipStream_t stream) {
     HIP_TRY(hipMemsetAsync(ctx->unit_counter, 0, sizeof(uint32_t), stream));
     const int spp = cam->sqrt_spp * cam->sqrt_spp;
     const int ppg = spp >= kBlock ? 1 : kBlock / spp;
@@ -160,7 +209,7 @@ int render_megakernel(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_cam
 
     RenderLaunch rl;
     rl.seed = seed;
-    rl.rows = ctx->rows;
+    rl.rows = rows;
     rl.n_rows = n_rows;
     rl.x0 = x0; rl.x1 = x1;
     rl.pixels_per_group = ppg;
@@ -174,13 +223,44 @@ int render_megakernel(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_cam
     return BDPT_OK;
 }
 
+// launch shape of the persistent traversal kernels and of the stage kernels for one scene
+int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCfg& cfg) {
+    const Knobs& kn = ctx->knobs;
+    cfg.lds_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuQuadNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
+    cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
+    if (!cfg.lds_scene) cfg.lds_bytes = 0;
+    cfg.top_nodes = (uint32_t)kn.lds_kb * 1024u / 128u;
+    cfg.lds_stack = kn.lds_stack;
+    int per_cu = 1;
+    HIP_TRY(wf_prepare_traverse(cfg, &per_cu));
+    // Three traversal workgroups per CU (3 x 88 registers per SIMD lane) leave room for TWO waves of a shading kernel
+    // (<= 120 registers) on every SIMD; with four, one fits.  More resident traversal waves only thrash L1 on large
+    // scenes anyway.  Measured: 3 beats 4 by about 1 % on every workload.
+    if (per_cu > 3) per_cu = 3;
+    if (kn.blocks_per_cu > 0) per_cu = kn.blocks_per_cu;
+    cfg.persistent_blocks = ctx->cu_count * per_cu;
+    cfg.refill_threshold = kn.refill;
+    cfg.leaf_threshold = kn.leaf;
+    cfg.leaf_inner = kn.leaf_inner > 0 ? kn.leaf_inner : (cfg.leaf_threshold > 1 ? cfg.leaf_threshold / 2 : 1);
+    cfg.chunk = (uint32_t)kn.chunk;   // measured: the cursor is one address, and its atomics cost more than a coarser split
+    cfg.stream_blocks = ctx->cu_count * 8;
+    return BDPT_OK;
+}
+
+// true when the four-wide hierarchy of the scene fits the traversal stack of the pipeline's kernels
+bool pipeline_can_walk(const bdpt_scene* scene) { return (int)scene->host.sah_stack + 3 <= kQuadStackEntries; }
+
 // ---- wavefront pipeline: batches of samples stream through per-stage kernels (wavefront.h)
 // Several batches are in flight at once, each on its own internal stream with its own workspace:
 // every bounce of a batch ends with the few longest rays of that bounce, and while one batch sits in
 // such a tail the waves of the other batches keep the chip busy.  Nothing in the pipeline waits for
 // the host: kernels whose queue turned out empty return at once.
-int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, uint64_t seed, int x0, int x1,
-                     int64_t n_owned, double* d_fb, int stats_mode, bool time_stages, hipStream_t stream) {
+// fixed_ws != null: the per-sample state lives in that caller-provided region of fixed_bytes bytes and nothing is
+// allocated; otherwise in the context's own allocation, grown on demand up to the context's workspace limit.
+int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, uint64_t seed, const int32_t* rows,
+                     int x0, int x1, int64_t n_owned, double* d_fb, int stats_mode, bool time_stages, hipStream_t stream,
+                     void* fixed_ws, size_t fixed_bytes) {
+    const Knobs& kn = ctx->knobs;
     const int depth = cam->max_depth;
     const int64_t spp = (int64_t)cam->sqrt_spp * cam->sqrt_spp;
     // A connection needs an eye vertex that is neither delta nor on an emitter (camera.h:441, material.h:35-37), i.e.
@@ -192,27 +272,40 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const size_t vslots = connections ? 2 * (size_t)(depth > 0 ? depth : 1) : 0;
     const uint32_t vis_words = connections ? (uint32_t)((depth > 0 ? depth : 1) + 63) / 64 : 0;
     const size_t shadow_per_slot = connections ? (size_t)(depth > 0 ? depth : 1) : 0;
-    if ((int)scene->host.sah_stack + 3 > kQuadStackEntries)
-        return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+    if (!pipeline_can_walk(scene)) return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     if (n_owned >= ((int64_t)1 << 31)) return fail(BDPT_ERR_UNSUPPORTED, "more than 2^31 pixels in one call");
     // bytes of state per sample slot
     const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 6 + vslots * 10 * sizeof(double) +
                             vis_words * sizeof(unsigned long long) + shadow_per_slot * 8 * sizeof(double);
+    const size_t n_counters = 8 + 6 * (size_t)(depth > 0 ? depth : 1);
     // Wavefront state of all batches in flight.  Large batches mean few, long launches (a frame is tens of thousands
-    // of them), so the state takes most of what the device has free: up to kWfWorkspaceBudget of the 288 GB.
-    size_t budget = (size_t)kWfWorkspaceBudget;
-    {
+    // of them), so a host that wants the last tenth of throughput raises the limit (bdpt_context_set_workspace_limit).
+    size_t budget;
+    if (fixed_ws) {
+        budget = fixed_bytes;
+    } else if (kn.budget_gb > 0) {
+        budget = (size_t)kn.budget_gb << 30;
+    } else {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const size_t avail = (free_b + ctx->wf_blob_bytes) / 10 * 7;
-        if (avail < budget) budget = avail;
-        const int gb = env_int("BDPT_WF_BUDGET_GB", 0);
-        if (gb > 0 && gb <= 224) budget = (size_t)gb << 30;
+        const size_t reach = free_b + ctx->wf_blob_bytes;
+        if (ctx->workspace_limit) {
+            budget = ctx->workspace_limit;
+            if (budget > reach / 10 * 9) budget = reach / 10 * 9;
+        } else {
+            budget = kDefaultWorkspaceLimit;
+            if (budget > reach / 4) budget = reach / 4;
+        }
     }
-    int want_streams = env_int("BDPT_WF_STREAMS", 4);
-    want_streams = want_streams < 1 ? 1 : (want_streams > kWfStreams ? kWfStreams : want_streams);
-    int64_t ns_target = (int64_t)(budget / want_streams / per_slot);
-    const int64_t ns_cap = (int64_t)1 << env_int("BDPT_WF_BATCH_LOG2", 26);
+    int want_streams = kn.streams;
+    // room for the 256-byte alignment of the 14 arrays of a workspace and for its counters
+    const size_t per_stream_overhead = 16 * 256 + align256(n_counters * 4);
+    if (budget / want_streams <= per_stream_overhead + per_slot * (size_t)spp) want_streams = 1;
+    if (budget <= per_stream_overhead + per_slot * (size_t)spp)
+        return fail(BDPT_ERR_UNSUPPORTED, fixed_ws ? "the samples of one pixel exceed the static workspace (samples per pixel x depth too large for bdpt_render_device_static)"
+                                                   : "samples per pixel exceed the wavefront batch capacity");
+    int64_t ns_target = (int64_t)((budget / want_streams - per_stream_overhead) / per_slot);
+    const int64_t ns_cap = (int64_t)1 << kn.batch_log2;
     if (ns_target > ns_cap) ns_target = ns_cap;
     if (spp > ns_target) return fail(BDPT_ERR_UNSUPPORTED, "samples per pixel exceed the wavefront batch capacity");
     int64_t pixels_per_batch = ns_target / spp;
@@ -224,7 +317,6 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     if (pixels_per_batch > 2 && pixels_per_batch % 2 == 0) pixels_per_batch--;
     const uint64_t ns = (uint64_t)(pixels_per_batch * spp);
     const uint64_t shadow_cap = ns * shadow_per_slot;
-    const size_t n_counters = 8 + 6 * (size_t)(depth > 0 ? depth : 1);
     const int64_t n_batches = (n_owned + pixels_per_batch - 1) / pixels_per_batch;
     const int n_streams = (int)(n_batches < want_streams ? n_batches : want_streams);
 
@@ -240,24 +332,50 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     // allocation than when they are neighbours (a total that large without the spacing does not help).  A frame big
     // enough to notice therefore spreads its workspaces over the whole budget even if it needs less.
     size_t per_stream = off;
-    if (per_stream * (size_t)n_streams >= ((size_t)4 << 30)) {
+    if (!fixed_ws && per_stream * (size_t)n_streams >= ((size_t)4 << 30)) {
         const size_t spread = (budget / (size_t)n_streams) & ~(size_t)255;
         if (spread > per_stream) per_stream = spread;
     }
     const size_t need = per_stream * (size_t)n_streams;
-    if (ctx->wf_blob_bytes < need) {
-        if (ctx->wf_blob) (void)hipFree(ctx->wf_blob);
-        ctx->wf_blob = nullptr;
-        ctx->wf_blob_bytes = 0;
-        HIP_TRY(hipMalloc(&ctx->wf_blob, need));
-        ctx->wf_blob_bytes = need;
+    char* ws_base;
+    if (fixed_ws) {
+        if (need > fixed_bytes) return fail(BDPT_ERR_UNSUPPORTED, "internal: static workspace layout exceeds its size");
+        ws_base = static_cast<char*>(fixed_ws);
+    } else {
+        if (ctx->wf_blob_bytes < need) {
+            if (ctx->wf_blob) (void)hipFree(ctx->wf_blob);
+            ctx->wf_blob = nullptr;
+            ctx->wf_blob_bytes = 0;
+            HIP_TRY(hipMalloc(&ctx->wf_blob, need));
+            ctx->wf_blob_bytes = need;
+        }
+        ws_base = static_cast<char*>(ctx->wf_blob);
+    }
+    // Upper bound of |direction| over all rays of the frame (the traversal kernels scale a per-triangle threshold with
+    // it): camera rays run from the lens to a point of the viewport, every other ray is a unit vector, or a unit
+    // vector plus fuzz (<= 1) times a unit vector (material.h:75).
+    float ray_len = 2.0f;
+    {
+        const double disk = std::sqrt(cam->defocus_disk_u[0] * cam->defocus_disk_u[0] + cam->defocus_disk_u[1] * cam->defocus_disk_u[1] + cam->defocus_disk_u[2] * cam->defocus_disk_u[2]) +
+                            std::sqrt(cam->defocus_disk_v[0] * cam->defocus_disk_v[0] + cam->defocus_disk_v[1] * cam->defocus_disk_v[1] + cam->defocus_disk_v[2] * cam->defocus_disk_v[2]);
+        for (int corner = 0; corner < 4; corner++) {
+            const double i = (corner & 1) ? cam->image_width + 1.0 : -1.0, j = (corner & 2) ? cam->image_height + 1.0 : -1.0;
+            double l2 = 0.0;
+            for (int k = 0; k < 3; k++) {
+                const double c = cam->pixel00_loc[k] + i * cam->pixel_delta_u[k] + j * cam->pixel_delta_v[k] - cam->center[k];
+                l2 += c * c;
+            }
+            const float l = (float)((std::sqrt(l2) + (cam->defocus_angle > 0 ? disk : 0.0)) * 1.001);
+            if (!(l <= ray_len)) ray_len = l;        // (a NaN bound stays: every hit is then re-checked)
+        }
     }
     WfBuffers wbs[kWfStreams];
     for (int s = 0; s < n_streams; s++) {
-        char* base = static_cast<char*>(ctx->wf_blob) + per_stream * (size_t)s;
+        char* base = ws_base + per_stream * (size_t)s;
         WfBuffers& wb = wbs[s];
         wb.ray = reinterpret_cast<double*>(base + o_ray); wb.thr = reinterpret_cast<double*>(base + o_thr);
         wb.hit = reinterpret_cast<double*>(base + o_hit); wb.result = reinterpret_cast<double*>(base + o_res);
+        wb.tmax = nullptr;
         wb.hit_tri = reinterpret_cast<int32_t*>(base + o_tri); wb.ctr = reinterpret_cast<uint32_t*>(base + o_ctr);
         wb.counts = reinterpret_cast<uint32_t*>(base + o_cnt);
         wb.queue[0] = reinterpret_cast<uint32_t*>(base + o_q0); wb.queue[1] = reinterpret_cast<uint32_t*>(base + o_q1);
@@ -265,35 +383,12 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         wb.vtx = reinterpret_cast<double*>(base + o_vtx); wb.vis = reinterpret_cast<unsigned long long*>(base + o_vis);
         wb.shadow = reinterpret_cast<double*>(base + o_sh); wb.counters = reinterpret_cast<uint32_t*>(base + o_counters);
         wb.ns = ns; wb.shadow_cap = shadow_cap; wb.vis_words = vis_words;
+        wb.ray_len_ptr = nullptr;
+        wb.ray_len = ray_len;
     }
 
     WfLaunchCfg cfg;
-    cfg.lds_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuQuadNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
-    cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
-    if (!cfg.lds_scene) cfg.lds_bytes = 0;
-    {
-        int kb = env_int("BDPT_WF_LDS_KB", 16);
-        if (kb < 1) kb = 1;
-        if (kb > 128) kb = 128;
-        cfg.top_nodes = (uint32_t)kb * 1024u / 128u;
-    }
-    cfg.lds_stack = env_int("BDPT_WF_LDS_STACK", 8);
-    if (cfg.lds_stack < 0) cfg.lds_stack = 0;
-    if (cfg.lds_stack > kQuadStackEntries) cfg.lds_stack = kQuadStackEntries;
-    int per_cu = 1;
-    HIP_TRY(wf_prepare_traverse(cfg, &per_cu));
-    // Three traversal workgroups per CU (3 x 88 registers per SIMD lane) leave room for TWO waves of a shading kernel
-    // (<= 120 registers) on every SIMD; with four, one fits.  More resident traversal waves only thrash L1 on large
-    // scenes anyway.  Measured: 3 beats 4 by about 1 % on every workload.
-    if (per_cu > 3) per_cu = 3;
-    per_cu = env_int("BDPT_WF_BLOCKS_PER_CU", per_cu);
-    cfg.persistent_blocks = ctx->cu_count * per_cu;
-    cfg.refill_threshold = env_int("BDPT_WF_REFILL", 16);
-    cfg.leaf_threshold = env_int("BDPT_WF_LEAF", 32);
-    cfg.leaf_inner = env_int("BDPT_WF_LEAF_INNER", cfg.leaf_threshold > 1 ? cfg.leaf_threshold / 2 : 1);
-    if (cfg.leaf_inner < 1) cfg.leaf_inner = 1;
-    cfg.chunk = (uint32_t)env_int("BDPT_WF_CHUNK", 512);   // measured: the cursor is one address, and its atomics cost more than a coarser split
-    cfg.stream_blocks = ctx->cu_count * 8;
+    { int rc = make_launch_cfg(ctx, scene, cfg); if (rc != BDPT_OK) return rc; }
 
     const GpuCamera gcam = to_gpu_camera(*cam);
     unsigned long long* stats = stats_mode ? ctx->stats : nullptr;
@@ -337,7 +432,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
 
         WfBatch b;
         b.seed = seed;
-        b.rows = ctx->rows;
+        b.rows = rows;
         b.row_w = x1 - x0; b.x0 = x0;
         b.first_pixel = first;
         b.n_pixels = (int32_t)((n_owned - first < pixels_per_batch) ? (n_owned - first) : pixels_per_batch);
@@ -373,7 +468,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         if (connections) HIP_TRY(wf_conn_prepare(gcam, wb, b, conn_count, cfg, stats, st));
         for (int a = 0; a < depth && connections; a++) {
             HIP_TRY(wf_conn_gen(scene->dev, gcam, wb, a, conn_count, shadow_count(a), cfg, stats, st));
-            { int rc = timed(1, st, [&] { return wf_occlude(scene->dev, wb, shadow_count(a), shadow_cursor(a), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
+            { int rc = timed(1, st, [&] { return wf_occlude(scene->dev, wb, shadow_count(a), 0, shadow_cursor(a), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
             HIP_TRY(wf_conn_accum(scene->dev, gcam, wb, a, conn_count, cfg, st));
         }
         HIP_TRY(wf_resolve(gcam, wb, b, d_fb, cfg, st));
@@ -386,8 +481,9 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     return BDPT_OK;
 }
 
+// fixed_ws != null: nothing is allocated - the row table and the per-sample state live in that region
 int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, const bdpt_render_params* p,
-                double* d_fb, hipStream_t stream) {
+                double* d_fb, hipStream_t stream, void* fixed_ws = nullptr, size_t fixed_bytes = 0) {
     if (!ctx || !scene || !cam || !p || !d_fb) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
     if (scene->ctx != ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "scene belongs to another context");
     if (cam->image_width <= 0 || cam->image_height <= 0) return fail(BDPT_ERR_INVALID_ARGUMENT, "empty image");
@@ -406,36 +502,108 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     const bool want_stats = stats_mode != 0;
     const bool want_time = (p->flags & BDPT_RENDER_TIME_KERNEL) != 0;
     const bool time_stages = (p->flags & BDPT_RENDER_TIME_STAGES) != 0;
+    const bool unidirectional = (p->flags & BDPT_RENDER_UNIDIRECTIONAL) != 0;     // single-kernel path only
+    // Reference-equivalent counters need the reference's traversal of every shadow ray: that is the single-kernel
+    // path, which also takes over when the four-wide hierarchy is deeper than the pipeline's traversal stack.
+    // Everything else runs the wavefront pipeline unless the caller asks otherwise.
+    const bool single_kernel = stats_mode == 1 || unidirectional || (p->flags & BDPT_RENDER_MEGAKERNEL) || !pipeline_can_walk(scene);
+    if (fixed_ws && (single_kernel || time_stages))
+        return fail(BDPT_ERR_UNSUPPORTED, pipeline_can_walk(scene)
+                        ? "bdpt_render_device_static supports the flags BDPT_RENDER_COUNT_WORK and BDPT_RENDER_TIME_KERNEL only"
+                        : "BVH deeper than the traversal stack (the single-kernel path that would render it allocates)");
     ctx->stats_valid = false;
     ctx->stage_valid = false;
-    if (want_stats) HIP_TRY(hipMemsetAsync(ctx->stats, 0, sizeof(unsigned long long) * kStatWords, stream));
-    if (x0 >= x1 || y0 >= y1) { ctx->stats_valid = want_stats; return BDPT_OK; }
-
-    std::vector<int32_t> rows;
-    for (int j = y0; j < y1; j++)
-        if ((j / shard_rows) % shard_count == p->shard_index) rows.push_back(j);
-    if (rows.empty()) { ctx->stats_valid = want_stats; return BDPT_OK; }
-
-    int rc = ensure_rows(ctx, rows.size());
-    if (rc != BDPT_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->rows, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));      // `rows` is a stack-lifetime host buffer
-
-    const int64_t n_owned = (int64_t)rows.size() * (x1 - x0);
     ctx->timing_valid = false;
+    if (want_stats) HIP_TRY(hipMemsetAsync(ctx->stats, 0, sizeof(unsigned long long) * kStatWords, stream));
     if (want_time) HIP_TRY(hipEventRecord(ctx->ev_start, stream));
-    // Reference-equivalent counters need the reference's traversal of every shadow ray: that is the
-    // single-kernel path.  Everything else runs the wavefront pipeline unless the caller asks otherwise.
-    const bool unidirectional = (p->flags & BDPT_RENDER_UNIDIRECTIONAL) != 0;     // single-kernel path only
-    if (stats_mode == 1 || unidirectional || (p->flags & BDPT_RENDER_MEGAKERNEL))
-        rc = render_megakernel(ctx, scene, cam, p->seed, (int32_t)rows.size(), x0, x1, n_owned, d_fb, stats_mode, unidirectional,
-                               stream);
-    else
-        rc = render_wavefront(ctx, scene, cam, p->seed, x0, x1, n_owned, d_fb, stats_mode, time_stages, stream);
-    if (rc != BDPT_OK) return rc;
-    ctx->stage_valid = time_stages && !(stats_mode == 1 || unidirectional || (p->flags & BDPT_RENDER_MEGAKERNEL));
+
+    // owned rows: j in [y0, y1) with (j / shard_rows) % shard_count == shard_index; the table is filled on the device
+    int64_t n_rows = 0;
+    if (x0 < x1 && y0 < y1)
+        n_rows = wf_owned_rows_before(y1, shard_rows, shard_count, p->shard_index) - wf_owned_rows_before(y0, shard_rows, shard_count, p->shard_index);
+    if (n_rows > 0) {
+        int32_t* rows;
+        if (fixed_ws) {
+            const size_t rows_bytes = align256(sizeof(int32_t) * (size_t)n_rows);
+            if (rows_bytes >= fixed_bytes) return fail(BDPT_ERR_UNSUPPORTED, "image too tall for the static workspace");
+            rows = static_cast<int32_t*>(fixed_ws);
+            fixed_ws = static_cast<char*>(fixed_ws) + rows_bytes;
+            fixed_bytes -= rows_bytes;
+        } else {
+            int rc = ensure_rows(ctx, (size_t)n_rows);
+            if (rc != BDPT_OK) return rc;
+            rows = ctx->rows;
+        }
+        HIP_TRY(wf_fill_rows(rows, y0, y1, shard_rows, shard_count, p->shard_index, stream));
+        const int64_t n_owned = n_rows * (x1 - x0);
+        int rc;
+        if (single_kernel)
+            rc = render_megakernel(ctx, scene, cam, p->seed, rows, (int32_t)n_rows, x0, x1, n_owned, d_fb, stats_mode, unidirectional, stream);
+        else
+            rc = render_wavefront(ctx, scene, cam, p->seed, rows, x0, x1, n_owned, d_fb, stats_mode, time_stages, stream, fixed_ws, fixed_bytes);
+        if (rc != BDPT_OK) return rc;
+        ctx->stage_valid = time_stages && !single_kernel;
+    }
     if (want_time) { HIP_TRY(hipEventRecord(ctx->ev_stop, stream)); ctx->timing_valid = true; }
     ctx->stats_valid = want_stats;
+    return BDPT_OK;
+}
+
+// ---- ray and visibility queries through the traversal kernels of the pipeline
+// Queries are processed in pieces of at most kQueryPiece so that the context's query workspace stays bounded.
+constexpr uint64_t kQueryPiece = (uint64_t)1 << 22;
+
+int trace_closest_pipeline(bdpt_context* ctx, const bdpt_scene* scene, const double* d_rays, uint64_t n, double* d_hits, hipStream_t stream) {
+    WfLaunchCfg cfg;
+    { int rc = make_launch_cfg(ctx, scene, cfg); if (rc != BDPT_OK) return rc; }
+    const uint64_t piece = n < kQueryPiece ? n : kQueryPiece;
+    size_t off = 0;
+    auto take = [&off](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+    const size_t o_ray = take(piece * 6 * 8), o_tmax = take(piece * 8), o_hit = take(piece * 8), o_tri = take(piece * 4), o_cur = take(256);   // cursor, then the ray length bound
+    { int rc = ensure_query_ws(ctx, off); if (rc != BDPT_OK) return rc; }
+    char* base = static_cast<char*>(ctx->query_ws);
+    WfBuffers wb{};
+    wb.ray = reinterpret_cast<double*>(base + o_ray);
+    double* tmax = reinterpret_cast<double*>(base + o_tmax);
+    wb.tmax = tmax;
+    wb.hit = reinterpret_cast<double*>(base + o_hit);
+    wb.hit_tri = reinterpret_cast<int32_t*>(base + o_tri);
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(base + o_cur);
+    float* ray_len = reinterpret_cast<float*>(cursor + 1);
+    wb.ray_len_ptr = ray_len;
+    wb.ns = piece;
+    for (uint64_t first = 0; first < n; first += piece) {
+        const uint32_t m = (uint32_t)(n - first < piece ? n - first : piece);
+        const double* rays = d_rays + 8 * first;
+        HIP_TRY(hipMemsetAsync(cursor, 0, 2 * sizeof(uint32_t), stream));
+        HIP_TRY(wf_rays_in(rays, m, wb, tmax, ray_len, stream));
+        HIP_TRY(wf_extend(scene->dev, wb, nullptr, nullptr, m, cursor, cfg, nullptr, stream));
+        HIP_TRY(wf_hits_out(scene->dev, rays, m, wb, d_hits + 11 * first, stream));
+    }
+    return BDPT_OK;
+}
+
+int visible_pipeline(bdpt_context* ctx, const bdpt_scene* scene, const double* d_pairs, uint64_t n, uint8_t* d_out, hipStream_t stream) {
+    WfLaunchCfg cfg;
+    { int rc = make_launch_cfg(ctx, scene, cfg); if (rc != BDPT_OK) return rc; }
+    const uint64_t piece = n < kQueryPiece ? n : kQueryPiece;
+    size_t off = 0;
+    auto take = [&off](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+    const size_t o_sh = take(piece * 8 * 8), o_vis = take(piece * 8), o_cur = take(256);
+    { int rc = ensure_query_ws(ctx, off); if (rc != BDPT_OK) return rc; }
+    char* base = static_cast<char*>(ctx->query_ws);
+    WfBuffers wb{};
+    wb.shadow = reinterpret_cast<double*>(base + o_sh);
+    wb.vis = reinterpret_cast<unsigned long long*>(base + o_vis);
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(base + o_cur);
+    wb.ns = piece; wb.shadow_cap = piece; wb.vis_words = 1;
+    for (uint64_t first = 0; first < n; first += piece) {
+        const uint32_t m = (uint32_t)(n - first < piece ? n - first : piece);
+        HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), stream));
+        HIP_TRY(wf_pairs_in(d_pairs + 6 * first, m, wb, stream));
+        HIP_TRY(wf_occlude(scene->dev, wb, nullptr, m, cursor, cfg, nullptr, stream));
+        HIP_TRY(wf_visible_out(wb, m, d_out + first, stream));
+    }
     return BDPT_OK;
 }
 
@@ -463,6 +631,7 @@ int bdpt_context_create(int device_index, bdpt_context** out) {
     if (!ctx) return fail(BDPT_ERR_OUT_OF_MEMORY, "host allocation failed");
     ctx->device = device_index;
     ctx->cu_count = prop.multiProcessorCount;
+    ctx->knobs = read_knobs();
     if (hipMalloc(&ctx->unit_counter, 256) != hipSuccess || hipMalloc(&ctx->stats, 256) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming) != hipSuccess) {
@@ -489,6 +658,7 @@ int bdpt_context_destroy(bdpt_context* ctx) {
     if (ctx->unit_counter) (void)hipFree(ctx->unit_counter);
     if (ctx->stats) (void)hipFree(ctx->stats);
     if (ctx->wf_blob) (void)hipFree(ctx->wf_blob);
+    if (ctx->query_ws) (void)hipFree(ctx->query_ws);
     for (int i = 0; i < kWfStreams; i++) {
         if (ctx->wf_streams[i]) (void)hipStreamDestroy(ctx->wf_streams[i]);
         if (ctx->wf_join[i]) (void)hipEventDestroy(ctx->wf_join[i]);
@@ -498,6 +668,19 @@ int bdpt_context_destroy(bdpt_context* ctx) {
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;
+    return BDPT_OK;
+}
+
+int bdpt_context_set_workspace_limit(bdpt_context* ctx, uint64_t bytes) {
+    if (!ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "null context");
+    ctx->workspace_limit = (size_t)bytes;
+    return BDPT_OK;
+}
+
+int bdpt_context_set_query_walker(bdpt_context* ctx, int walker) {
+    if (!ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "null context");
+    if (walker != BDPT_WALKER_PIPELINE && walker != BDPT_WALKER_REFERENCE_TREE) return fail(BDPT_ERR_INVALID_ARGUMENT, "unknown walker");
+    ctx->query_walker = walker;
     return BDPT_OK;
 }
 
@@ -577,6 +760,7 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     d.light_accum = reinterpret_cast<const double*>(base + off_lacc);
     d.light_total_area = h.light_total_area;
     d.coord_bound = h.coord_bound;
+    d.bary_margin = h.bary_margin;
     d.n_nodes = (uint32_t)h.nodes.size();
     d.n_tris = (uint32_t)h.tris.size();
     d.n_mats = (uint32_t)h.mats.size();
@@ -627,7 +811,11 @@ int bdpt_trace_closest_device(bdpt_context* ctx, const bdpt_scene* scene, const 
                               void* stream) {
     if (!ctx || !scene || (n && (!d_rays || !d_hits))) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
     if (scene->ctx != ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "scene belongs to another context");
+    if (n == 0) return BDPT_OK;
     DeviceGuard guard(ctx->device);
+    if (ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene))
+        return trace_closest_pipeline(ctx, scene, static_cast<const double*>(d_rays), n, static_cast<double*>(d_hits),
+                                      static_cast<hipStream_t>(stream));
     HIP_TRY(launch_trace_closest(scene->dev, static_cast<const double*>(d_rays), n, static_cast<double*>(d_hits), nullptr,
                                  static_cast<hipStream_t>(stream)));
     return BDPT_OK;
@@ -648,7 +836,11 @@ int bdpt_trace_closest(bdpt_context* ctx, const bdpt_scene* scene, const double*
     do {
         if ((e = hipMemcpy(d_rays, rays, n * 8 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
         if (stats && (e = hipMemset(ctx->stats, 0, sizeof(unsigned long long) * kStatWords)) != hipSuccess) break;
-        if ((e = launch_trace_closest(scene->dev, d_rays, n, d_hits, stats ? ctx->stats : nullptr, nullptr)) != hipSuccess) break;
+        // counters have the reference's meaning, so a counting call walks the reference's own tree
+        if (!stats && ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene)) {
+            rc = trace_closest_pipeline(ctx, scene, d_rays, n, d_hits, nullptr);
+            if (rc != BDPT_OK) break;
+        } else if ((e = launch_trace_closest(scene->dev, d_rays, n, d_hits, stats ? ctx->stats : nullptr, nullptr)) != hipSuccess) break;
         if ((e = hipMemcpy(hits, d_hits, n * 11 * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) break;
         if (stats) {
             unsigned long long h[kStatWords];
@@ -658,7 +850,7 @@ int bdpt_trace_closest(bdpt_context* ctx, const bdpt_scene* scene, const double*
     } while (0);
     (void)hipFree(d_rays);
     (void)hipFree(d_hits);
-    if (e != hipSuccess) rc = hip_fail(e, "bdpt_trace_closest");
+    if (rc == BDPT_OK && e != hipSuccess) rc = hip_fail(e, "bdpt_trace_closest");
     return rc;
 }
 
@@ -672,13 +864,18 @@ int bdpt_visible(bdpt_context* ctx, const bdpt_scene* scene, const double* pairs
     HIP_TRY(hipMalloc(&d_pairs, n * 6 * sizeof(double)));
     hipError_t e = hipMalloc(&d_out, n);
     if (e != hipSuccess) { (void)hipFree(d_pairs); return hip_fail(e, "hipMalloc(visible)"); }
+    int rc = BDPT_OK;
     do {
         if ((e = hipMemcpy(d_pairs, pairs, n * 6 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
-        if ((e = launch_visible(scene->dev, d_pairs, n, d_out, nullptr)) != hipSuccess) break;
+        if (ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene)) {
+            rc = visible_pipeline(ctx, scene, d_pairs, n, d_out, nullptr);
+            if (rc != BDPT_OK) break;
+        } else if ((e = launch_visible(scene->dev, d_pairs, n, d_out, nullptr)) != hipSuccess) break;
         if ((e = hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost)) != hipSuccess) break;
     } while (0);
     (void)hipFree(d_pairs);
     (void)hipFree(d_out);
+    if (rc != BDPT_OK) return rc;
     if (e != hipSuccess) return hip_fail(e, "bdpt_visible");
     return BDPT_OK;
 }

@@ -161,6 +161,27 @@ BDPT_DEV bool tri_test(const GpuTri& tr, V3 o, V3 d, double tmin, double tmax, d
     return true;
 }
 
+// The same test without the upper end of the interval: true when everything but `t <= tmax` holds; also returns
+// the determinant.  (tri_test(..., tmax) == tri_candidate(...) && t <= tmax, bit for bit.)
+BDPT_DEV bool tri_candidate(const GpuTri& tr, V3 o, V3 d, double tmin, double& t_out, double& u_out, double& v_out,
+                            double& det_out) {
+    V3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+    V3 pvec = cross(d, e2);
+    double det = dot(e1, pvec);
+    if (__builtin_fabs(det) < 1e-8) return false;
+    double inv_det = 1.0 / det;
+    V3 tvec = sub(o, ld3(tr.v0));
+    double u = dot(tvec, pvec) * inv_det;
+    if (u < 0.0 || u > 1.0) return false;
+    V3 qvec = cross(tvec, e1);
+    double v = dot(d, qvec) * inv_det;
+    if (v < 0.0 || u + v > 1.0) return false;
+    double t = dot(e2, qvec) * inv_det;
+    if (!(tmin <= t)) return false;
+    t_out = t; u_out = u; v_out = v; det_out = det;
+    return true;
+}
+
 // bvh_node::hit (src/acceleration/bvh.h:50-59) + aabb::hit (src/acceleration/aabb.h:41-66) as a walk
 // over the threaded tree.  The reference hands every later sibling the closest t found so far
 // (bvh.h:56), so one running `closest` reproduces its intervals; visiting order is the

@@ -215,6 +215,11 @@ static size_t scene_lds_bytes(const SceneDev& sc) {
 
 bool scene_fits_lds(const SceneDev& sc) { return scene_lds_bytes(sc) <= kSceneLdsLimit; }
 
+// The render kernel keeps 12 KiB of per-sample colours in LDS beside the tables; together they stay within the
+// 64 KiB a kernel may request without raising its dynamic LDS limit.
+constexpr size_t kRenderSampleLds = sizeof(double) * kBlock * 6;
+static bool render_scene_fits_lds(const SceneDev& sc) { return scene_lds_bytes(sc) + kRenderSampleLds <= kSceneLdsLimit; }
+
 // Resident workgroups per CU of the render kernel variant a launch would pick (sizes the persistent grid).
 template <int STATS, bool LDS>
 static hipError_t occupancy_of(size_t shmem, int* n) {
@@ -227,8 +232,8 @@ static hipError_t occupancy_of_unidirectional(size_t shmem, int* n) {
 }
 
 hipError_t render_blocks_per_cu(const SceneDev& sc, int stats_mode, bool unidirectional, int* out) {
-    const bool lds = scene_fits_lds(sc);
-    const size_t shmem = sizeof(double) * kBlock * 6 + (lds ? scene_lds_bytes(sc) : 0);
+    const bool lds = render_scene_fits_lds(sc);
+    const size_t shmem = kRenderSampleLds + (lds ? scene_lds_bytes(sc) : 0);
     int n = 0;
     hipError_t e;
     if (unidirectional) {
@@ -246,8 +251,8 @@ hipError_t render_blocks_per_cu(const SceneDev& sc, int stats_mode, bool unidire
 
 hipError_t launch_render(const SceneDev& sc, const GpuCamera& cam, const RenderLaunch& rl, int grid_blocks, int stats_mode,
                          bool unidirectional, hipStream_t stream) {
-    const bool lds = scene_fits_lds(sc);
-    size_t shmem = sizeof(double) * kBlock * 6 + (lds ? scene_lds_bytes(sc) : 0);
+    const bool lds = render_scene_fits_lds(sc);
+    size_t shmem = kRenderSampleLds + (lds ? scene_lds_bytes(sc) : 0);
     dim3 grid(grid_blocks), block(kBlock);
     if (unidirectional) {
         if (stats_mode != kStatsOff) {

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
 
 namespace bdpt {
@@ -90,7 +91,12 @@ struct Builder {
     }
 };
 
-inline double vx(const double* v, int k) { return v[k]; }
+// std::fmin / std::fmax as the C library the reference is built against evaluates them (glibc, x86-64: one
+// minsd / maxsd instruction with the first argument as destination): of two equal operands - +0 and -0 compare
+// equal - the SECOND is returned.  A compiler's inline expansion may return the other zero, and the box tables are
+// compared bit for bit.
+inline double second_fmin(double x, double y) { return (x < y) ? x : ((y != y) ? x : y); }
+inline double second_fmax(double x, double y) { return (x > y) ? x : ((y != y) ? x : y); }
 
 
 // ---------------------------------------------------------------------------------------------
@@ -353,8 +359,8 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
         a.normal[0] = inv * nx; a.normal[1] = inv * ny; a.normal[2] = inv * nz;
         a.area = 0.5 * nlen;
         for (int k = 0; k < 3; k++) {
-            const double lo = std::fmin(v0[k], std::fmin(v1[k], v2[k]));
-            const double hi = std::fmax(v0[k], std::fmax(v1[k], v2[k]));
+            const double lo = second_fmin(v0[k], second_fmin(v1[k], v2[k]));      // triangle.h:31-36
+            const double hi = second_fmax(v0[k], second_fmax(v1[k], v2[k]));
             if (lo <= hi) { btris[i].box.lo[k] = lo; btris[i].box.hi[k] = hi; }
             else { btris[i].box.lo[k] = hi; btris[i].box.hi[k] = lo; }
         }
@@ -423,7 +429,10 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
     // closest-hit hierarchy over the same triangles (referenced by their position in `stris`)
     {
         SahBuilder sb;
-        if (const char* v = std::getenv("BDPT_SAH_MIN_LEAF")) sb.min_leaf = (size_t)std::atoi(v);
+        if (const char* v = std::getenv("BDPT_SAH_MIN_LEAF")) {      // a leaf reference has room for 1..4 triangles
+            const int m = std::atoi(v);
+            sb.min_leaf = (size_t)(m < 1 ? 1 : (m > 4 ? 4 : m));
+        }
         if (const char* v = std::getenv("BDPT_SAH_BOX_COST")) sb.box_cost = std::atof(v);
         sb.refs.resize(out.stris.size());
         for (size_t p = 0; p < out.stris.size(); p++) {
@@ -463,10 +472,25 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
         for (const SahRef& r : sb.refs)
             for (int k = 0; k < 3; k++) out.coord_bound = std::fmax(out.coord_bound, std::fmax(std::fabs(r.lo[k]), std::fabs(r.hi[k])));
         out.coord_bound = (double)round_up(out.coord_bound * 1.0000002);     // covers the outward FP32 rounding of the boxes
+        // Hits the traversal kernels re-check against the reference's own tree (wavefront.hip, "exact ties"): a hit
+        // within bary_margin of the triangle's outline, or by a ray within 1e-4 rad of the triangle's plane
+        // (|det| = |d . (e1 x e2)| below 1e-4 |d| |e1 x e2|; the threshold without the |d| is kept per triangle, as
+        // FP32 bits in the otherwise unused material field).  The margin argument needs a hit inside the outline
+        // to be at least ~64 ulp of the coordinates inside the triangle's box on every axis the box is not thin
+        // (< 1e-4, where the reference pads) on: bary_margin * 1e-4 >= 64 ulp(4 * coord_bound).  A triangle whose
+        // box is thin on two axes has no such axis pair and is always re-checked (threshold +infinity).
+        out.bary_margin = std::fmax(1e-6, 64.0 * 0x1p-52 * 4.0 * out.coord_bound / 1e-4);
         out.xtris.resize(sb.leaf_order.size());
         for (size_t k = 0; k < sb.leaf_order.size(); k++) {
             GpuTri t = out.stris[sb.leaf_order[k]];
+            const uint32_t id = (uint32_t)t.pad;
             t.pad = (int32_t)sb.leaf_order[k];
+            int thin_axes = 0;
+            for (int a = 0; a < 3; a++) thin_axes += (btris[id].box.hi[a] - btris[id].box.lo[a] < 1e-4) ? 1 : 0;
+            float graze = round_up(1e-4 * 2.0 * out.aux[id].area);       // |e1 x e2| = 2 area
+            if (thin_axes >= 2) graze = std::numeric_limits<float>::infinity();
+            static_assert(sizeof(float) == sizeof(int32_t), "FP32 bits in an int32 field");
+            std::memcpy(&t.material, &graze, sizeof graze);
             out.xtris[k] = t;
         }
     }

@@ -21,6 +21,7 @@ struct HostScene {
     std::vector<GpuQuadNode> xnodes;     // closest-hit hierarchy (binned SAH, four children per record)
     std::vector<GpuTri> xtris;           // its triangles in leaf order (pad = position in stris)
     double coord_bound = 0.0;            // largest |coordinate| of its boxes
+    double bary_margin = 1e-6;           // see SceneDev::bary_margin
     uint32_t sah_stack = 0;              // most entries its traversal stack can hold at once
     bool has_lambertian = false;         // some triangle has a lambertian material (the only connectable kind of vertex)
     std::vector<GpuTriAux> aux;

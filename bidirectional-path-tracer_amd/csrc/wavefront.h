@@ -17,6 +17,7 @@ struct WfBuffers {
     double* ray;          // [6][ns]  origin, direction of the ray to trace next
     double* thr;          // [3][ns]  path throughput
     double* hit;          // [ns]     t of the last closest hit
+    const double* tmax;   // [ns]     upper end of the interval of a closest-hit ray, or null: +infinity (trace_path, camera.h:336)
     int32_t* hit_tri;     // [ns]     position of the hit triangle in the leaf-ordered table, or -1
     uint32_t* ctr;        // [ns]     random numbers drawn so far by the sample
     double* result;       // [3][ns]  radiance of the sample
@@ -27,10 +28,15 @@ struct WfBuffers {
     uint32_t* conn_queue; // [ns]     samples that have both eye and light vertices
     double* shadow;       // [8][shadow_cap]  shadow rays: origin, direction, max_t, tag (slot, b)
     uint32_t* counters;   // queue sizes and work-distribution cursors, zeroed once per batch
+    const float* ray_len_ptr;  // upper bound of |direction| over the closest-hit rays: *ray_len_ptr, or ray_len when null
+    float ray_len;
     uint64_t ns;
     uint64_t shadow_cap;
     uint32_t vis_words;
 };
+
+// wb.hit_tri value of a ray whose closest hit the traversal kernel leaves to the walk over the reference's own tree
+constexpr int32_t kHitRedo = -2;
 
 // entries of the closest-hit walk's stack (up to three pushes per level of the four-wide tree)
 constexpr int kQuadStackEntries = 64;
@@ -76,7 +82,8 @@ hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBa
                            const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
 hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
                        uint32_t* shadow_count, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
-hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t* cursor,
+// number of queue entries: *shadow_count, or count_imm when shadow_count is null
+hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t count_imm, uint32_t* cursor,
                       const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
 hipError_t wf_conn_accum(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
                          const WfLaunchCfg& cfg, hipStream_t st);
@@ -85,6 +92,21 @@ hipError_t wf_resolve(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& 
 
 // sets the LDS limit of the traversal kernels for this launch shape and reports how many workgroups fit a CU
 hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu);
+
+// Table of the image rows a render call owns: rows j of [y0, y1) with (j / shard_rows) % shard_count == shard_index,
+// in increasing order.  wf_owned_rows_before(y, ...) is the number of owned rows below y (host arithmetic); the
+// kernel writes row j to rows[wf_owned_rows_before(j) - wf_owned_rows_before(y0)].
+int64_t wf_owned_rows_before(int64_t y, int shard_rows, int shard_count, int shard_index);
+hipError_t wf_fill_rows(int32_t* rows, int y0, int y1, int shard_rows, int shard_count, int shard_index, hipStream_t st);
+
+// Ray batches through the traversal kernels of the pipeline (bvh_node::hit / camera::visible for arrays of queries).
+// rays: n x 8 doubles (origin, direction, tmin, tmax) -> wb.ray / wb.tmax;  hits: n x 11 doubles (hit_record).
+// also raises *ray_len_out (zeroed by the caller) to the largest |direction|
+hipError_t wf_rays_in(const double* rays, uint32_t n, const WfBuffers& wb, double* tmax_out, float* ray_len_out, hipStream_t st);
+hipError_t wf_hits_out(const SceneDev& sc, const double* rays, uint32_t n, const WfBuffers& wb, double* hits, hipStream_t st);
+// pairs: n x 6 doubles (a, b) -> shadow-ray queue entries 0..n-1 (pair k answers in bit 0 of wb.vis[k]);  out: n bytes
+hipError_t wf_pairs_in(const double* pairs, uint32_t n, const WfBuffers& wb, hipStream_t st);
+hipError_t wf_visible_out(const WfBuffers& wb, uint32_t n, uint8_t* out, hipStream_t st);
 
 }  // namespace bdpt
 #endif

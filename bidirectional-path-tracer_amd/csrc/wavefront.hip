@@ -138,6 +138,35 @@ __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb,
 //    reference_reaches() confirms the reference's own boxes from its node up to the root, in the reference's
 //    arithmetic.  (Both kinds of query share one residual assumption: a box is not lost to rounding when the
 //    ray is inside it for less than ~1e-12 of its length around the hit point.)
+//
+// Exact ties.  The statement above - "a different hierarchy returns the reference's answer" - rests on the
+// reference reaching every triangle that would accept, i.e. on the boxes of its own tree passing aabb::hit for that
+// ray.  They do whenever the hit point lies inside them with a margin, and they may not when the ray only grazes
+// them: a hit on the outline of its triangle (a ray through a vertex touches the triangle's box in one point), a ray
+// almost inside the triangle's plane (u, v and t then carry a large rounding error), a hit at the lower end 0.001 of
+// the interval, or two hits at the same distance (coplanar surfaces: the second one's boxes are tested against an
+// interval that ends exactly where they begin, and rounding decides whether the reference ever tests it).  Such
+// hits are recognised by cheap sufficient conditions (grazes(), and a relative distance below 1e-9 between a hit
+// and the running closest distance).  A visibility ray then asks reference_reaches(); a closest-hit ray gives up
+// the walk and is marked kHitRedo: the kernel that reads the hit next (k_shade, k_hits_out) repeats the query with
+// the reference's own traversal (device_core.h: walk) for it.  About one ray in 10^5 takes that road.
+// Why the remaining hits are safe: the hit point p is inside the triangle by at least bary_margin in every
+// barycentric coordinate, hence inside the triangle's box - and every box above it - by bary_margin x the box's
+// extent on every axis where that extent is at least 1e-4; on an axis where the box is thinner the reference pads
+// its node boxes by 5e-5, or p lies ON a face of an unpadded larger box - on one axis only (triangles thin on two
+// axes are always re-checked), so the ray still runs inside that box on one side of p.  The slab arithmetic of
+// aabb.h:41-66 is accurate to a few ulp of the coordinates, far below those margins, and the interval it is
+// clipped to, [0.001, closest so far], contains t with the same margins unless one of the conditions above holds.
+constexpr double kTieRelative = 1e-9;
+
+// the triangle's grazing threshold (1e-4 |e1 x e2|, or +infinity for a triangle that is always re-checked) travels
+// as FP32 bits in the `material` field of the traversal hierarchy's triangle table
+BDPT_DEV bool grazes(const GpuTri& tr, double u, double v, double t, double det, double bary_margin, float ray_len) {
+    const float threshold = __int_as_float(tr.material);
+    return u < bary_margin || v < bary_margin || u + v > 1.0 - bary_margin || t < 0.001 + 1e-9 ||
+           __builtin_fabsf((float)det) < threshold * ray_len;
+}
+
 constexpr int kQuadStackDepth = kQuadStackEntries;
 constexpr int32_t kPop = (int32_t)0x80000000;   // neither an interior index (>= 0) nor a leaf reference
 
@@ -174,8 +203,10 @@ struct TopLdsMem {
 //   |b - o|/|d| * 1.5 * 2^-23  (d to FP32 and the reciprocal)  +  |o|/|d| * 2^-23  (o to FP32 and the product)
 //   + |t| * 2^-24  (the fma)   <=   (|b| + |o|) / |d| * 0.75 * 2^-21
 // and slack = (bound + |o|) * 2^-20 * |inv| (bound = largest |coordinate| of any box) is 2.6 times that.
-// A NaN (0 * inf, inf - inf: rays parallel to an axis) is dropped by min/max, i.e. that plane does not
-// constrain the interval - never a wrong cull.
+// A direction component of zero (or one so small that 1/d or o/d leaves the FP32 range) would give infinities and
+// NaNs here, so such an axis is left out: inv = 0 and (c_min, c_max) = (-inf, +inf) put no bound on the interval.
+// (The reference's own test, aabb.h:41-66, misses the box when the origin is outside that slab and passes
+// otherwise; leaving the axis out is the superset of both.)
 typedef float f2 __attribute__((ext_vector_type(2)));
 struct RayF32 {
     f2 inv[3];      // (1/d, 1/d)
@@ -190,9 +221,12 @@ BDPT_DEV RayF32 ray_f32(V3 o, V3 d, float bound) {
         const float of = (float)oo[a];
         const float c = -(of * inv);
         const float slack = (bound + __builtin_fabsf(of)) * 0x1p-20f * __builtin_fabsf(inv) * 1.000001f;
-        r.inv[a] = (f2){inv, inv};
+        // (x - x == 0) is false exactly for infinities and NaNs
+        const bool usable = (inv - inv == 0.0f) && (c - c == 0.0f) && (slack - slack == 0.0f);
+        r.inv[a] = usable ? (f2){inv, inv} : (f2){0.0f, 0.0f};
         // 1/d > 0: the min plane is the near one (gets -slack); 1/d < 0: the max plane is
-        r.c[a] = (inv >= 0.0f) ? (f2){c - slack, c + slack} : (f2){c + slack, c - slack};
+        r.c[a] = !usable ? (f2){-__builtin_inff(), __builtin_inff()}
+                         : ((inv >= 0.0f) ? (f2){c - slack, c + slack} : (f2){c + slack, c - slack});
     }
     return r;
 }
@@ -277,6 +311,10 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                              const int kLeafThreshold, const int kLeafInner, const double coord_bound, double* lds_stack, const int kLdsStack,
                              const uint32_t first_base) {
     const float bound_f32 = float_up(coord_bound);
+    const double bary_margin = sc.bary_margin;
+    // upper bound of |d| over the rays of this launch (visibility rays have unit directions)
+    const float ray_len = SHADOW ? 1.0001f : (wb.ray_len_ptr ? *wb.ray_len_ptr : wb.ray_len);
+    bool redo = false;                  // closest-hit rays: the walk met an exact tie, see above
     bool has = false;
     uint32_t slot = 0;
     int32_t cur = kPop;                 // interior record to visit next (when leaf_left == 0)
@@ -342,7 +380,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                         const uint64_t ns = wb.ns;
                         o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
                         d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
-                        tmax0 = kInf;
+                        tmax0 = wb.tmax ? wb.tmax[slot] : kInf;
                     }
                     if (!SHADOW || tmax0 >= 0.0) {              // a negative max_t marks an unused queue entry
                         rf = ray_f32(o, d, bound_f32);
@@ -351,6 +389,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                         leaf_left = 0;
                         sp = 0;
                         h.tri = -1;
+                        redo = false;
                         has = true;
                         if (STATS) n_rays++;
                     }
@@ -408,23 +447,29 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                 const GpuTri tr = mem.stri(leaf_next);
                 leaf_next++;
                 leaf_left--;
-                double t, u, v;
+                double t, u, v, det;
                 // triangle.h:63: accepted when tmin <= t <= closest (inclusive)
-                const bool inside = tri_test(tr, o, d, 0.001, closest, t, u, v);
+                const bool cand = tri_candidate(tr, o, d, 0.001, t, u, v, det);
+                const bool inside = cand && t <= closest;
                 if (STATS) { n_tri++; if (inside) n_tri_hits++; }
-                if (inside) {
-                    if (SHADOW) {
-                        // Away from both ends of the interval the boxes above an accepted triangle contain the hit
-                        // point with the ray well inside the interval, so they pass; only a hit at an end of the
-                        // interval (the far end point's own surface, t = max_t up to rounding) needs the check.
-                        const double margin = 1e-9 * closest + 1e-12;
-                        const bool at_an_end = (closest - t <= margin) || (t - 0.001 <= margin);
-                        if (!at_an_end || reference_reaches(sc, sc.sleaf[tr.pad], o, d, closest)) { h.tri = tr.pad; done = true; leaf_left = 0; }
+                if (SHADOW) {
+                    if (inside) {
+                        // Away from the ends of the interval and from the triangle's outline the boxes above an
+                        // accepted triangle contain the hit point with a margin, so they pass; a hit at the far end
+                        // (the far end point's own surface, t = max_t up to rounding: most unoccluded pairs) or a
+                        // grazing one counts only if the reference's own boxes let it through.
+                        const bool check = (closest - t <= 1e-9 * closest + 1e-12) || grazes(tr, u, v, t, det, bary_margin, ray_len);
+                        if (!check || reference_reaches(sc, sc.sleaf[tr.pad], o, d, closest)) { h.tri = tr.pad; done = true; leaf_left = 0; }
                     }
-                    // equal t: the reference keeps the triangle it visits later = larger position in
-                    // its leaf order (tr.pad)
-                    else if (t < closest || h.tri < 0 || tr.pad > h.tri) {
-                        closest = t; h.tri = tr.pad;           // the hit distance IS the running bound
+                } else if (cand) {
+                    const bool tie = __builtin_fabs(t - closest) <= kTieRelative * t;        // (false while closest is +infinity)
+                    if (inside || tie) {
+                        if (tie || grazes(tr, u, v, t, det, bary_margin, ray_len)) { redo = true; done = true; leaf_left = 0; }
+                        // equal t: the reference keeps the triangle it visits later = larger position in
+                        // its leaf order (tr.pad)
+                        else if (t < closest || h.tri < 0 || tr.pad > h.tri) {
+                            closest = t; h.tri = tr.pad;           // the hit distance IS the running bound
+                        }
                     }
                 }
                 if (leaf_left == 0 && !done) pop = true;
@@ -458,10 +503,10 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                     atomicOr(&wb.vis[(uint64_t)(bidx >> 6) * wb.ns + s], 1ull << (bidx & 63u));
                 }
             } else {
-                wb.hit_tri[slot] = h.tri;      // position in the reference's leaf order (k_shade turns it into the triangle id)
+                wb.hit_tri[slot] = redo ? kHitRedo : h.tri;      // position in the reference's leaf order (k_shade turns it into the triangle id)
                 // the barycentric coordinates of the hit are not kept: nothing on this path reads them (the
                 // reference's hit_record carries u, v for textures, and every texture here is a solid colour)
-                if (h.tri >= 0) wb.hit[slot] = closest;
+                if (!redo && h.tri >= 0) wb.hit[slot] = closest;
             }
             has = false;
         }
@@ -516,7 +561,8 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
     // entries to workgroups that start late because kernels of the other batches hold their place.
     const uint32_t waves_per_block = blockDim.x >> 6;
     uint32_t first_base;
-    if ((uint64_t)count <= (uint64_t)gridDim.x * waves_per_block * 64u) {
+    if ((uint64_t)count <= (uint64_t)gridDim.x * waves_per_block * 64u &&
+        (uint64_t)count <= (uint64_t)gridDim.x * waves_per_block * wave_chunk) {      // every entry has an owner
         if ((uint64_t)blockIdx.x * waves_per_block * wave_chunk >= count) return;       // the whole workgroup
         first_base = (blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * wave_chunk;
         cursor = nullptr;
@@ -544,6 +590,18 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
     }
 }
 
+// Triangle id (or -1) and distance of the closest hit the traversal kernel recorded for `slot`; a ray it marked
+// kHitRedo is traced here with the reference's own traversal (bvh_node::hit over the reference's tree).
+__device__ __attribute__((noinline)) int32_t redo_closest(const SceneDev& sc, V3 o, V3 d, double tmax, double& t) {
+    GlobalScene mem{sc.nodes, sc.tris};
+    Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    HitLite h;
+    h.tri = -1; h.t = 0; h.u = 0; h.v = 0;
+    if (!walk<kStatsOff, false>(mem, o, d, 0.001, tmax, h, c)) return -1;
+    t = h.t;
+    return h.tri;
+}
+
 // ------------------------------------------------------------------ shading of one bounce
 template <bool EYE, bool STATS, bool LAMBERT>
 __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
@@ -569,7 +627,12 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             int pi, pj, ps;
             if (!slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
             const int32_t pos = wb.hit_tri[slot];
-            const int32_t tri = pos < 0 ? -1 : sc.stris[pos].pad;      // leaf position -> triangle id
+            int32_t tri = pos < 0 ? -1 : sc.stris[pos].pad;      // leaf position -> triangle id
+            double t_hit = 0.0;
+            if (pos == kHitRedo)
+                tri = redo_closest(sc, mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]),
+                                   mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]), kInf, t_hit);
+            else if (pos >= 0) t_hit = wb.hit[slot];
             V3 T = mk(wb.thr[slot], wb.thr[ns + slot], wb.thr[2 * ns + slot]);
             if (tri < 0) {
                 if (EYE) {   // camera.h:337-338: background_contrib (0) += throughput * background
@@ -581,7 +644,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
             V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
             HitLite h;
-            h.tri = tri; h.t = wb.hit[slot]; h.u = 0; h.v = 0;
+            h.tri = tri; h.t = t_hit; h.u = 0; h.v = 0;
             const uint32_t ctr0 = wb.ctr[slot];
             Rng rng = slot_rng(cam, b, slot, ctr0);
             Bounce bo;
@@ -844,9 +907,140 @@ __global__ __launch_bounds__(kBlock) void k_resolve(GpuCamera cam, WfBuffers wb,
     }
 }
 
+// ------------------------------------------------------------------ owned rows of a render call
+BDPT_DEV int64_t owned_rows_before(int64_t y, int shard_rows, int shard_count, int shard_index) {
+    const int64_t cycle = (int64_t)shard_rows * shard_count;
+    int64_t part = y % cycle - (int64_t)shard_index * shard_rows;
+    part = part < 0 ? 0 : (part > shard_rows ? shard_rows : part);
+    return (y / cycle) * shard_rows + part;
+}
+__global__ __launch_bounds__(kBlock) void k_fill_rows(int32_t* rows, int y0, int y1, int shard_rows, int shard_count, int shard_index) {
+    const int j = y0 + (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (j >= y1 || (j / shard_rows) % shard_count != shard_index) return;
+    rows[owned_rows_before(j, shard_rows, shard_count, shard_index) - owned_rows_before(y0, shard_rows, shard_count, shard_index)] = j;
+}
+
+// ------------------------------------------------------------------ ray batches through the pipeline's traversal kernels
+__global__ __launch_bounds__(kBlock) void k_rays_in(const double* rays, uint32_t n, WfBuffers wb, double* tmax_out, float* ray_len_out) {
+    float longest = 0.0f;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+        const double* in = rays + 8 * (uint64_t)k;
+#pragma unroll
+        for (int c = 0; c < 6; c++) wb.ray[(uint64_t)c * wb.ns + k] = in[c];
+        tmax_out[k] = in[7];
+        const float l = __builtin_sqrtf((float)(in[3] * in[3] + in[4] * in[4] + in[5] * in[5])) * 1.0001f;
+        longest = (l > longest || l != l) ? (l != l ? __builtin_inff() : l) : longest;      // a NaN direction: re-check every hit
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) longest = __builtin_fmaxf(longest, __shfl_down(longest, off, 64));
+    // non-negative floats order like their bit patterns
+    if (lane_id() == 0 && longest > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(ray_len_out), __float_as_uint(longest));
+}
+
+// hit_record of the closest hit (hittable.h:10-27): the traversal kernel reports the triangle and t; u, v are the
+// same triangle's test evaluated once more (identical arithmetic, identical bits).  The traversal kernel's lower
+// bound is the 0.001 of trace_path (camera.h:336); a ray with another tmin takes the reference's own walk here.
+__global__ __launch_bounds__(kBlock) void k_hits_out(SceneDev sc, const double* rays, uint32_t n, WfBuffers wb, double* hits) {
+    Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+        const double* in = rays + 8 * (uint64_t)k;
+        const V3 o = mk(in[0], in[1], in[2]), d = mk(in[3], in[4], in[5]);
+        HitLite h;
+        h.tri = -1; h.t = 0; h.u = 0; h.v = 0;
+        if (in[6] == 0.001) {
+            const int32_t pos = wb.hit_tri[k];
+            if (pos == kHitRedo) {
+                GlobalScene mem{sc.nodes, sc.tris};
+                if (!walk<kStatsOff, false>(mem, o, d, in[6], in[7], h, c)) h.tri = -1;
+            } else if (pos >= 0) {
+                h.tri = sc.stris[pos].pad;
+                double t, u, v;
+                if (tri_test(sc.tris[h.tri], o, d, 0.001, kInf, t, u, v)) { h.t = t; h.u = u; h.v = v; }
+            }
+        } else {
+            GlobalScene mem{sc.nodes, sc.tris};
+            if (!walk<kStatsOff, false>(mem, o, d, in[6], in[7], h, c)) h.tri = -1;
+        }
+        double* out = hits + 11 * (uint64_t)k;
+        if (h.tri < 0) {
+            out[0] = -1.0;
+#pragma unroll
+            for (int q = 1; q < 11; q++) out[q] = 0.0;
+        } else {
+            const V3 outward = ld3(sc.aux[h.tri].normal);
+            const bool front = dot(d, outward) < 0;
+            const V3 nrm = front ? outward : neg(outward);
+            const V3 p = add(o, scl(h.t, d));
+            out[0] = (double)h.tri; out[1] = h.t; out[2] = h.u; out[3] = h.v; out[4] = front ? 1.0 : 0.0;
+            out[5] = p.x; out[6] = p.y; out[7] = p.z; out[8] = nrm.x; out[9] = nrm.y; out[10] = nrm.z;
+        }
+    }
+}
+
+// camera::visible (camera.h:425-436) up to the traversal: the shadow ray of the pair (a, b) as queue entry k
+__global__ __launch_bounds__(kBlock) void k_pairs_in(const double* pairs, uint32_t n, WfBuffers wb) {
+    const uint64_t cap = wb.shadow_cap;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+        const double* in = pairs + 6 * (uint64_t)k;
+        const V3 a = mk(in[0], in[1], in[2]), b = mk(in[3], in[4], in[5]);
+        wb.vis[k] = 0ull;
+        const V3 dir = sub(b, a);
+        const double dist = len(dir);
+        double max_t = -1.0;                    // a negative max_t marks an entry without a ray: "not visible"
+        V3 origin = a, dir_unit = dir;
+        if (dist > 0) {
+            dir_unit = divs(dir, dist);
+            origin = add(a, scl(0.001, dir_unit));
+            if (dist - 0.001 > 0) max_t = dist - 0.001;
+        }
+        wb.shadow[k] = origin.x; wb.shadow[cap + k] = origin.y; wb.shadow[2 * cap + k] = origin.z;
+        wb.shadow[3 * cap + k] = dir_unit.x; wb.shadow[4 * cap + k] = dir_unit.y; wb.shadow[5 * cap + k] = dir_unit.z;
+        wb.shadow[6 * cap + k] = max_t;
+        wb.shadow[7 * cap + k] = __longlong_as_double((long long)((unsigned long long)k << 16));
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_visible_out(WfBuffers wb, uint32_t n, uint8_t* out) {
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) out[k] = (uint8_t)(wb.vis[k] & 1ull);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------ launchers
+int64_t wf_owned_rows_before(int64_t y, int shard_rows, int shard_count, int shard_index) {
+    const int64_t cycle = (int64_t)shard_rows * shard_count;
+    int64_t part = y % cycle - (int64_t)shard_index * shard_rows;
+    part = part < 0 ? 0 : (part > shard_rows ? shard_rows : part);
+    return (y / cycle) * shard_rows + part;
+}
+
+hipError_t wf_fill_rows(int32_t* rows, int y0, int y1, int shard_rows, int shard_count, int shard_index, hipStream_t st) {
+    if (y1 <= y0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_rows, dim3((unsigned)((y1 - y0 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rows, y0, y1, shard_rows,
+                       shard_count, shard_index);
+    return hipGetLastError();
+}
+
+static unsigned batch_grid(uint32_t n) {
+    const uint32_t b = (n + kBlock - 1) / kBlock;
+    return b > 4096u ? 4096u : (b ? b : 1u);
+}
+hipError_t wf_rays_in(const double* rays, uint32_t n, const WfBuffers& wb, double* tmax_out, float* ray_len_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_rays_in, dim3(batch_grid(n)), dim3(kBlock), 0, st, rays, n, wb, tmax_out, ray_len_out);
+    return hipGetLastError();
+}
+hipError_t wf_hits_out(const SceneDev& sc, const double* rays, uint32_t n, const WfBuffers& wb, double* hits, hipStream_t st) {
+    hipLaunchKernelGGL(k_hits_out, dim3(batch_grid(n)), dim3(kBlock), 0, st, sc, rays, n, wb, hits);
+    return hipGetLastError();
+}
+hipError_t wf_pairs_in(const double* pairs, uint32_t n, const WfBuffers& wb, hipStream_t st) {
+    hipLaunchKernelGGL(k_pairs_in, dim3(batch_grid(n)), dim3(kBlock), 0, st, pairs, n, wb);
+    return hipGetLastError();
+}
+hipError_t wf_visible_out(const WfBuffers& wb, uint32_t n, uint8_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_visible_out, dim3(batch_grid(n)), dim3(kBlock), 0, st, wb, n, out);
+    return hipGetLastError();
+}
+
 // Sets the LDS limit of one traversal kernel (more than 64 KiB of dynamic LDS has to be requested) and reports
 // how many of its workgroups fit a CU.
 template <bool SHADOW, bool STATS, bool LDS_SCENE>
@@ -920,9 +1114,9 @@ hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* qu
     return launch_traverse<false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
 }
 
-hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t* cursor,
+hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t count_imm, uint32_t* cursor,
                       const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    return launch_traverse<true>(sc, wb, nullptr, shadow_count, 0, cursor, cfg, stats, st);
+    return launch_traverse<true>(sc, wb, nullptr, shadow_count, count_imm, cursor, cfg, stats, st);
 }
 
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,

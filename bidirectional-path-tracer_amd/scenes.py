@@ -312,7 +312,58 @@ class _Rows:
         return self.a if dtype is None else self.a.astype(dtype, copy=False)
 
 
+def mixed_materials_3k(image_width: int = 40, samples_per_pixel: int = 16, max_depth: int = 8) -> FlatScene:
+    """Cornell room (both boxes) with three 960-triangle spheres - lambertian, glass, fuzzy metal - and a small
+    emissive sphere: 3 140 triangles, all four materials, many light triangles; too large for the LDS copy of the
+    whole scene, so the traversal kernels read it from global memory."""
+    s = cornell_box(image_width, samples_per_pixel, max_depth, short_box=True)
+    blue = s.add_material(Material(LAMBERTIAN, (.2, .3, .7)))
+    glass = s.add_material(Material(DIELECTRIC, ior=1.5))
+    steel = s.add_material(Material(METAL, (.8, .8, .85), fuzz=0.15))
+    glow = s.add_material(Material(DIFFUSE_LIGHT, (4.0, 3.0, 2.0)))
+    add_uv_sphere(s, (140.0, 245.0, 150.0), 75.0, blue)
+    add_uv_sphere(s, (400.0, 110.0, 130.0), 90.0, glass)
+    add_uv_sphere(s, (300.0, 420.0, 330.0), 70.0, steel)
+    add_uv_sphere(s, (100.0, 80.0, 420.0), 35.0, glow, 8, 16)
+    s.camera.file_name = "mixed3k.png"
+    return s
+
+
+def coplanar_stack(image_width: int = 32, samples_per_pixel: int = 16, max_depth: int = 6) -> FlatScene:
+    """Axis-aligned geometry chosen to land on the ties of the reference's traversal: a floor, a second quad lying
+    exactly in the floor's plane (same t for both), a third partly overlapping both, an unrotated box standing
+    flush on the floor (its faces coincide with faces of the boxes of the BVH nodes above them), a thin slab
+    (1e-5 thick: its triangle boxes are padded), walls meeting at exact corners, and an emissive quad."""
+    s = FlatScene()
+    grey = s.add_material(Material(LAMBERTIAN, (.6, .6, .6)))
+    red = s.add_material(Material(LAMBERTIAN, (.7, .2, .2)))
+    green = s.add_material(Material(LAMBERTIAN, (.2, .7, .2)))
+    mirror = s.add_material(Material(METAL, (.9, .9, .9), fuzz=0.0))
+    glass = s.add_material(Material(DIELECTRIC, ior=1.5))
+    light = s.add_material(Material(DIFFUSE_LIGHT, (10.0, 10.0, 10.0)))
+    add_quad_triangles(s, (0, 0, 0), (8, 0, 0), (0, 0, 8), grey)              # floor
+    add_quad_triangles(s, (2, 0, 2), (4, 0, 0), (0, 0, 4), red)               # in the floor's plane
+    add_quad_triangles(s, (4, 0, 1), (3, 0, 0), (0, 0, 3), green)             # overlaps both
+    add_quad_triangles(s, (0, 0, 8), (8, 0, 0), (0, 6, 0), grey)              # back wall
+    add_quad_triangles(s, (0, 0, 0), (0, 0, 8), (0, 6, 0), red)               # left wall
+    add_quad_triangles(s, (8, 0, 0), (0, 6, 0), (0, 0, 8), green)             # right wall
+    add_quad_triangles(s, (0, 6, 0), (0, 0, 8), (8, 0, 0), grey)              # ceiling
+    add_box_triangles(s, (1, 0, 5), (3, 2, 7), grey)                          # flush on the floor, axis-aligned
+    add_box_triangles(s, (5, 0, 4.5), (7, 3, 6.5), mirror)
+    add_box_triangles(s, (3.5, 0, 2.5), (4.5, 1, 3.5), glass)
+    add_box_triangles(s, (2, 2.5, 2), (6, 2.50001, 4), red)                   # thin slab
+    add_quad_triangles(s, (3, 5.999, 3), (2, 0, 0), (0, 0, 2), light)
+    s.camera = Camera(aspect_ratio=1.0, image_width=image_width, samples_per_pixel=samples_per_pixel, max_depth=max_depth,
+                      background=(0.0, 0.0, 0.0), vfov=60.0, lookfrom=(4, 3, -6), lookat=(4, 2.5, 4), vup=(0, 1, 0),
+                      file_name="coplanar.png")
+    return s
+
+
 # ------------------------------------------------------------------------------- stand-ins for the shipped scenes
+# Both scene files of the reference (scenes/glass-of-water.yaml, scenes/coffee_machine.yaml) name Wavefront OBJ
+# meshes that are not part of its checkout.  The stand-ins below are procedural meshes written out under exactly
+# those file names (write_standin_assets), so that the reference's own YAML files render unchanged through the
+# scene loader; the builders further down assemble the same FlatScene directly (same triangles, same order).
 def _lathe(profile, segments):
     """Triangles (numpy, M x 9) of the surface of revolution of the (r, y) polyline `profile`
     around the y axis.  Profile points with r == 0 produce single triangles (no degenerate ones)."""
@@ -341,74 +392,227 @@ def _orient_outward(tris):
     return tris
 
 
-def _add_mesh(scene: FlatScene, tris, mat: int, offset=(0.0, 0.0, 0.0)):
-    off = np.array(offset, dtype=np.float64)
+def _mesh_of(build) -> np.ndarray:
+    """Triangles (M x 9) that `build(scene, material)` adds to an empty scene."""
+    tmp = FlatScene()
+    m = tmp.add_material(Material(LAMBERTIAN, (0, 0, 0)))
+    build(tmp, m)
+    return np.array(tmp.vertices, dtype=np.float64).reshape(-1, 9)
+
+
+def _box_mesh(a, b, rotate_y_degrees=0.0, translate=(0.0, 0.0, 0.0)):
+    return _mesh_of(lambda s, m: add_box_triangles(s, a, b, m, rotate_y_degrees, translate))
+
+
+def _offset(tris, off):
+    return tris + np.tile(np.array(off, dtype=np.float64), 3)[None, :]
+
+
+def _grid_quad(q, u, v, nu, nv):
+    """The parallelogram (q, u, v) as nu x nv quads of two triangles each (add_quad_triangles per cell)."""
+    def build(s, m):
+        q_, u_, v_ = (np.array(x, dtype=np.float64) for x in (q, u, v))
+        for a in range(nu):
+            for b in range(nv):
+                add_quad_triangles(s, tuple(q_ + u_ * (a / nu) + v_ * (b / nv)), tuple(u_ / nu), tuple(v_ / nv), m)
+    return _mesh_of(build)
+
+
+def _add_mesh(scene: FlatScene, tris, mat: int):
     for t in tris:
-        scene.add_triangle(t[0:3] + off, t[3:6] + off, t[6:9] + off, mat)
+        scene.add_triangle(t[0:3], t[3:6], t[6:9], mat)
 
 
-def glass_of_water_standin(image_width: int = 1920, image_height: int = 1080, samples_per_pixel: int = 1024,
-                           max_depth: int = 12, detail: float = 1.0) -> FlatScene:
-    """Procedural stand-in for /root/reference/scenes/glass-of-water.yaml, whose OBJ meshes
-    (scenes/data/glass-of-water/models/Mesh0xx.obj) are not part of the reference checkout.
-
-    Camera, material table and the area-light quad are the YAML's values (glass-of-water.yaml:1-46,
-    128-136); the geometry is a lathe-turned glass holding water with ice blocks (two of them with
-    enclosed 'AirIce' pockets), on a metal floor in front of a curved metal backdrop - the same
-    material mix (every surface except the light is a delta material) at a comparable triangle
-    count (~45 k at detail 1)."""
-    s = FlatScene()
-    c = 147.0 / 255.0                                             # the YAML's [147,147,147] after 0-255 scaling
-    backdrop = s.add_material(Material(METAL, (147 * (1.0 / 255.0),) * 3, fuzz=0.1))
-    floor = s.add_material(Material(METAL, (147 * (1.0 / 255.0),) * 3, fuzz=0.1))
-    water = s.add_material(Material(DIELECTRIC, ior=1.33))
-    ice = s.add_material(Material(DIELECTRIC, ior=1.31))
-    glass = s.add_material(Material(DIELECTRIC, ior=1.5))
-    air_ice = s.add_material(Material(DIELECTRIC, ior=0.763))
-    light = s.add_material(Material(DIFFUSE_LIGHT, (15.9155, 27.0563, 31.831)))
-    del c
-
+def glass_of_water_meshes(detail: float = 1.0):
+    """[(file name relative to the YAML, material name, triangles M x 9)] in the order of the `surfaces:` list of
+    /root/reference/scenes/glass-of-water.yaml:47-123: a lathe-turned glass holding water with ice blocks (four of
+    them with enclosed 'AirIce' pockets), on a metal floor in front of a curved metal backdrop - the scene's
+    material mix (every surface except the light is a delta material), ~55 k triangles at detail 1."""
     seg = max(16, int(256 * detail))
     steps = max(4, int(40 * detail))
     # glass: outer wall up, rim, inner wall down, thick base (closed profile from the axis back to the axis)
     outer = [(2.0 + 0.45 * (k / steps) ** 1.5, 0.02 + 6.4 * k / steps) for k in range(steps + 1)]
     inner = [(r - 0.16, y) for r, y in reversed(outer) if y >= 0.55]
     prof = [(0.0, 0.02)] + outer + [(outer[-1][0] - 0.08, outer[-1][1] + 0.04)] + inner + [(0.0, inner[-1][1])]
-    _add_mesh(s, _orient_outward(_lathe(prof, seg)), glass)
+    glass = _orient_outward(_lathe(prof, seg))
     # water body just inside the inner wall, flat surface at y = 4.4
     wsteps = max(3, int(24 * detail))
     y_lo, y_hi = inner[-1][1] + 0.01, 4.4
     rad = lambda y: 2.0 + 0.45 * ((y - 0.02) / 6.4) ** 1.5 - 0.16 - 0.01
     wprof = [(0.0, y_lo)] + [(rad(y_lo + (y_hi - y_lo) * k / wsteps), y_lo + (y_hi - y_lo) * k / wsteps)
                              for k in range(wsteps + 1)] + [(0.0, y_hi)]
-    _add_mesh(s, _orient_outward(_lathe(wprof, seg)), water)
-    # ice blocks floating in the water, two with air pockets inside
-    add_box_triangles(s, (-0.6, 0.0, -0.6), (0.6, 1.2, 0.6), ice, 25.0, (-0.75, 3.7, 0.3))
-    add_box_triangles(s, (-0.55, 0.0, -0.55), (0.55, 1.1, 0.55), ice, -40.0, (0.8, 3.6, -0.4))
-    add_box_triangles(s, (-0.5, 0.0, -0.5), (0.5, 1.0, 0.5), ice, 10.0, (0.1, 3.9, 0.9))
-    add_box_triangles(s, (-0.2, 0.0, -0.2), (0.2, 0.4, 0.2), air_ice, 25.0, (-0.75, 4.1, 0.3))
-    add_box_triangles(s, (-0.15, 0.0, -0.15), (0.15, 0.3, 0.15), air_ice, -40.0, (0.8, 4.0, -0.4))
+    water = _orient_outward(_lathe(wprof, seg))
+    # two drops of water on the floor beside the glass (closed lathe shapes)
+    drop = lambda r, h, n: _orient_outward(_lathe([(0.0, 0.0)] + [(r * math.sin(0.5 * math.pi * k / n) ** 0.8, h * (1 - math.cos(0.5 * math.pi * k / n)))
+                                                                   for k in range(1, n + 1)] + [(0.0, h)], max(12, seg // 8)))
+    drop_a = _offset(drop(0.35, 0.12, max(3, steps // 6)), (3.4, 0.001, 1.2))
+    drop_b = _offset(drop(0.22, 0.09, max(3, steps // 6)), (-3.1, 0.001, 2.0))
+    # ice blocks floating in the water, four of them with an air pocket inside
+    ice = [_box_mesh((-0.6, 0.0, -0.6), (0.6, 1.2, 0.6), 25.0, (-0.75, 3.7, 0.3)),
+           _box_mesh((-0.55, 0.0, -0.55), (0.55, 1.1, 0.55), -40.0, (0.8, 3.6, -0.4)),
+           _box_mesh((-0.5, 0.0, -0.5), (0.5, 1.0, 0.5), 10.0, (0.1, 3.9, 0.9)),
+           _box_mesh((-0.45, 0.0, -0.45), (0.45, 0.9, 0.45), 55.0, (-0.2, 3.55, -0.95)),
+           _box_mesh((-0.4, 0.0, -0.4), (0.4, 0.8, 0.4), -15.0, (0.9, 3.75, 0.85))]
+    air = [_box_mesh((-0.2, 0.0, -0.2), (0.2, 0.4, 0.2), 25.0, (-0.75, 4.1, 0.3)),
+           _box_mesh((-0.15, 0.0, -0.15), (0.15, 0.3, 0.15), -40.0, (0.8, 4.0, -0.4)),
+           _box_mesh((-0.12, 0.0, -0.12), (0.12, 0.25, 0.12), 10.0, (0.1, 4.3, 0.9)),
+           _box_mesh((-0.1, 0.0, -0.1), (0.1, 0.2, 0.1), 55.0, (-0.2, 3.9, -0.95))]
     # floor and curved backdrop (a swept quarter cylinder), both metal
-    add_quad_triangles(s, (-40.0, 0.0, 30.0), (80.0, 0.0, 0.0), (0.0, 0.0, -42.0), floor)
+    floor = _mesh_of(lambda s, m: add_quad_triangles(s, (-40.0, 0.0, 30.0), (80.0, 0.0, 0.0), (0.0, 0.0, -42.0), m))
     bseg = max(8, int(48 * detail))
     bx = max(4, int(24 * detail))
     R = 12.0
-    for k in range(bseg):
-        t0, t1 = 0.5 * math.pi * k / bseg, 0.5 * math.pi * (k + 1) / bseg
-        z0, y0 = -12.0 - R * math.sin(t0), R - R * math.cos(t0)
-        z1, y1 = -12.0 - R * math.sin(t1), R - R * math.cos(t1)
-        for j in range(bx):
-            xa, xb = -40.0 + 80.0 * j / bx, -40.0 + 80.0 * (j + 1) / bx
-            add_quad_triangles(s, (xa, y0, z0), (xb - xa, 0.0, 0.0), (0.0, y1 - y0, z1 - z0), backdrop)
-    add_quad_triangles(s, (-40.0, R, -12.0 - R), (80.0, 0.0, 0.0), (0.0, 30.0, 0.0), backdrop)
-    # the YAML's area light, as its two indexed triangles
+
+    def backdrop_build(s, m):
+        for k in range(bseg):
+            t0, t1 = 0.5 * math.pi * k / bseg, 0.5 * math.pi * (k + 1) / bseg
+            z0, y0 = -12.0 - R * math.sin(t0), R - R * math.cos(t0)
+            z1, y1 = -12.0 - R * math.sin(t1), R - R * math.cos(t1)
+            for j in range(bx):
+                xa, xb = -40.0 + 80.0 * j / bx, -40.0 + 80.0 * (j + 1) / bx
+                add_quad_triangles(s, (xa, y0, z0), (xb - xa, 0.0, 0.0), (0.0, y1 - y0, z1 - z0), m)
+        add_quad_triangles(s, (-40.0, R, -12.0 - R), (80.0, 0.0, 0.0), (0.0, 30.0, 0.0), m)
+    backdrop = _mesh_of(backdrop_build)
+    d = "data/glass-of-water/models/"
+    return [(d + "Mesh008.obj", "WaterAir", water), (d + "Mesh005.obj", "WaterAir", drop_a), (d + "Mesh000.obj", "WaterAir", drop_b),
+            (d + "Mesh004.obj", "IceAir", ice[0]), (d + "Mesh010.obj", "IceAir", ice[1]),
+            (d + "Mesh009.obj", "AirIce", air[0]), (d + "Mesh012.obj", "AirIce", air[1]),
+            (d + "Mesh014.obj", "IceAir", ice[2]), (d + "Mesh015.obj", "AirIce", air[2]),
+            (d + "Mesh006.obj", "IceAir", ice[3]), (d + "Mesh002.obj", "AirIce", air[3]),
+            (d + "Mesh001.obj", "IceAir", ice[4]),
+            (d + "Mesh007.obj", "Backdrop", backdrop), (d + "Mesh011.obj", "Floor", floor), (d + "Mesh013.obj", "Glass", glass)]
+
+
+def glass_of_water_standin(image_width: int = 1920, image_height: int = 1080, samples_per_pixel: int = 1024,
+                           max_depth: int = 12, detail: float = 1.0) -> FlatScene:
+    """What the scene loader makes of /root/reference/scenes/glass-of-water.yaml with the stand-in meshes of
+    glass_of_water_meshes in place of the missing OBJ files, assembled directly: the YAML's material table
+    (glass-of-water.yaml:11-45, colours given in 0-255 scaled by 1/255 as scene_loader.h:81-92 does), its surfaces in
+    file order, its area light (:125-134) and its camera (:1-9) with resolution, samples and depth of the
+    benchmark configuration."""
+    s = FlatScene()
+    grey = (147 * (1.0 / 255.0),) * 3
+    # (ior = 0 for everything that is not a dielectric: what the scene loader stores there)
+    mats = {"Backdrop": s.add_material(Material(METAL, grey, fuzz=0.1, ior=0.0)),
+            "Floor": s.add_material(Material(METAL, grey, fuzz=0.1, ior=0.0)),
+            "WaterAir": s.add_material(Material(DIELECTRIC, ior=1.33)),
+            "IceAir": s.add_material(Material(DIELECTRIC, ior=1.31)),
+            "Glass": s.add_material(Material(DIELECTRIC, ior=1.5)),
+            "AirIce": s.add_material(Material(DIELECTRIC, ior=0.763)),
+            "Light": s.add_material(Material(DIFFUSE_LIGHT, (15.9155, 27.0563, 31.831), ior=0.0))}
+    for _, mat, tris in glass_of_water_meshes(detail):
+        _add_mesh(s, tris, mats[mat])
     lv = [(-2.53848244, 12.39156476, 24.58024509), (2.46151756, 12.39156524, 24.58024491),
           (2.46151804, 8.57023524, 27.80475491), (-2.53848196, 8.57023476, 27.80475509)]
-    s.add_triangle(lv[0], lv[1], lv[2], light)
-    s.add_triangle(lv[0], lv[2], lv[3], light)
+    s.add_triangle(lv[0], lv[1], lv[2], mats["Light"])
+    s.add_triangle(lv[0], lv[2], lv[3], mats["Light"])
     s.camera = Camera(aspect_ratio=float(image_width) / float(image_height), image_width=image_width,
                       samples_per_pixel=samples_per_pixel, max_depth=max_depth, background=(0.0, 0.0, 0.0), vfov=35.0,
                       lookfrom=(-0.08935849368572235, 2.694121837615967, 25.672550201416016),
                       lookat=(0.006514795124530792, 3.1010689735412598, 0.010185359977185726), vup=(0.0, 1.0, 0.0),
                       defocus_angle=0.0, focus_dist=10.0, file_name="glass_of_water.png")
     return s
+
+
+def coffee_machine_meshes(detail: float = 1.0):
+    """Stand-in meshes for /root/reference/scenes/coffee_machine.yaml:29-52 (data/coffee_maker/*.obj): a drip coffee
+    maker of lambertian plastic (black body, orange trim) with a metal hot plate, filter ring and riser tube and a
+    glass carafe with a thick wall, on a lambertian floor that curves up into a back wall.  The scene is about
+    half a unit across (the YAML's lights and camera fix the scale).  ~110 k triangles at detail 1."""
+    seg = max(12, int(192 * detail))
+    n = max(2, int(12 * detail))
+    ring = lambda prof, off, sg=seg: _offset(_orient_outward(_lathe(prof, sg)), off)
+    # body: base slab, back column, head that overhangs the carafe (tessellated boxes), all black plastic
+    def tess_box(a, b, k):
+        (x0, y0, z0), (x1, y1, z1) = a, b
+        parts = [_grid_quad((x0, y0, z1), (x1 - x0, 0, 0), (0, y1 - y0, 0), k, k), _grid_quad((x1, y0, z0), (x0 - x1, 0, 0), (0, y1 - y0, 0), k, k),
+                 _grid_quad((x0, y0, z0), (0, 0, z1 - z0), (0, y1 - y0, 0), k, k), _grid_quad((x1, y0, z1), (0, 0, z0 - z1), (0, y1 - y0, 0), k, k),
+                 _grid_quad((x0, y1, z1), (x1 - x0, 0, 0), (0, 0, z0 - z1), k, k), _grid_quad((x0, y0, z0), (x1 - x0, 0, 0), (0, 0, z1 - z0), k, k)]
+        return np.concatenate(parts)
+    black = np.concatenate([tess_box((-0.11, 0.0, -0.14), (0.11, 0.035, 0.12), n), tess_box((-0.09, 0.035, -0.14), (0.09, 0.34, -0.07), n),
+                            tess_box((-0.10, 0.27, -0.07), (0.10, 0.36, 0.10), n),
+                            ring([(0.0, 0.0), (0.018, 0.0), (0.018, 0.05), (0.012, 0.06), (0.0, 0.06)], (0.0, 0.17, 0.135), max(12, seg // 4))])   # carafe handle knob
+    # orange trim: lid of the head, a band round the base, the carafe's lid
+    orange = np.concatenate([tess_box((-0.102, 0.36, -0.072), (0.102, 0.375, 0.102), n), tess_box((-0.112, 0.012, -0.142), (0.112, 0.022, 0.122), max(2, n // 2)),
+                             ring([(0.0, 0.0), (0.052, 0.0), (0.056, 0.008), (0.03, 0.02), (0.012, 0.03), (0.0, 0.03)], (0.0, 0.2005, 0.03))])
+    # metal: hot plate, filter ring under the head, riser tube
+    metal = np.concatenate([ring([(0.0, 0.0), (0.075, 0.0), (0.078, 0.004), (0.075, 0.008), (0.0, 0.008)], (0.0, 0.0352, 0.03)),
+                            ring([(0.0, 0.0), (0.045, 0.0), (0.05, 0.03), (0.0, 0.03)], (0.0, 0.2395, 0.03)),
+                            ring([(0.0, 0.0), (0.006, 0.0), (0.006, 0.22), (0.0, 0.22)], (0.07, 0.04, -0.06), max(8, seg // 6))])
+    # glass carafe: outer wall up, rim, inner wall down (closed shell, 3 mm thick), standing on the hot plate
+    k = max(6, int(36 * detail))
+    outer = [(0.035 + 0.04 * math.sin(math.pi * (i / k) * 0.95) ** 0.8, 0.15 * i / k) for i in range(k + 1)]
+    inner = [(max(r - 0.003, 0.004), y) for r, y in reversed(outer) if y >= 0.004]
+    glass = ring([(0.0, 0.0)] + outer + inner + [(0.0, inner[-1][1])], (0.0, 0.0436, 0.03))
+    # floor curving up into a back wall
+    f = max(4, int(48 * detail))
+    parts = [_grid_quad((-0.9, 0.0, 0.9), (1.8, 0.0, 0.0), (0.0, 0.0, -1.2), f, f)]
+    Rr = 0.25
+    for i in range(f):
+        t0, t1 = 0.5 * math.pi * i / f, 0.5 * math.pi * (i + 1) / f
+        z0, y0 = -0.3 - Rr * math.sin(t0), Rr - Rr * math.cos(t0)
+        z1, y1 = -0.3 - Rr * math.sin(t1), Rr - Rr * math.cos(t1)
+        parts.append(_grid_quad((-0.9, y0, z0), (1.8, 0.0, 0.0), (0.0, y1 - y0, z1 - z0), f, 1))
+    parts.append(_grid_quad((-0.9, Rr, -0.3 - Rr), (1.8, 0.0, 0.0), (0.0, 0.9, 0.0), f, f // 2))
+    floor = np.concatenate(parts)
+    d = "data/coffee_maker/"
+    return [(d + "Plastic_Orange.obj", "Plastic_Orange", orange), (d + "Plastic_Black.obj", "Plastic_Black", black),
+            (d + "Metal.obj", "Metal", metal), (d + "Glass.obj", "Glass", glass), (d + "Floor.obj", "Floor", floor)]
+
+
+def coffee_machine_standin(image_width: int = 1920, image_height: int = 1080, samples_per_pixel: int = 512,
+                           max_depth: int = 10, detail: float = 1.0) -> FlatScene:
+    """What the scene loader makes of /root/reference/scenes/coffee_machine.yaml (materials :8-28, three light quads
+    :54-83, camera :1-6 with the defaults of src/camera.h:26-41 for what it leaves out) with the stand-in meshes,
+    assembled directly; resolution, samples and depth of the benchmark configuration (512 spp = 22 x 22 samples)."""
+    s = FlatScene()
+    mats = {"Plastic_Orange": s.add_material(Material(LAMBERTIAN, (255 * (1.0 / 255.0), 97 * (1.0 / 255.0), 3 * (1.0 / 255.0)), ior=0.0)),
+            "Plastic_Black": s.add_material(Material(LAMBERTIAN, (0.0, 0.0, 0.0), ior=0.0)),
+            "Glass": s.add_material(Material(DIELECTRIC, ior=1.5)),
+            "Metal": s.add_material(Material(METAL, (170 * (1.0 / 255.0),) * 3, fuzz=0.1, ior=0.0)),
+            "Floor": s.add_material(Material(LAMBERTIAN, (147 * (1.0 / 255.0),) * 3, ior=0.0)),
+            "Light": s.add_material(Material(DIFFUSE_LIGHT, (245.0, 245.0, 245.0), ior=0.0))}
+    for _, mat, tris in coffee_machine_meshes(detail):
+        _add_mesh(s, tris, mats[mat])
+    quads = [[(-0.359309, 0.449693, -0.010809), (-0.196537, 0.449693, 0.338256), (-0.196537, 0.000849009, 0.338256), (-0.359309, 0.000848979, -0.010809)],
+             [(0.320673, 0.027337, 0.228975), (0.320673, 0.476182, 0.228975), (0.325221, 0.476182, -0.136419), (0.325221, 0.027337, -0.136419)],
+             [(0.230128, 0.50385, 0.267372), (-0.230128, 0.50385, 0.267372), (-0.230128, 0.50385, -0.192885), (0.230128, 0.50385, -0.192885)]]
+    for v in quads:
+        s.add_triangle(v[0], v[1], v[2], mats["Light"])
+        s.add_triangle(v[0], v[2], v[3], mats["Light"])
+    s.camera = Camera(aspect_ratio=float(image_width) / float(image_height), image_width=image_width,
+                      samples_per_pixel=samples_per_pixel, max_depth=max_depth, background=(0.0, 0.0, 0.0), vfov=30.0,
+                      lookfrom=(-0.0029600381385535, 0.19830328226089478, 0.828150749206543),
+                      lookat=(0.002896534511819482, 0.16660931706428528, 0.022717338055372238), vup=(0.0, 1.0, 0.0),
+                      defocus_angle=0.0, focus_dist=10.0, file_name="image.png")
+    return s
+
+
+def write_obj(path: str, tris: np.ndarray) -> None:
+    """Triangle soup as a Wavefront OBJ file (`v` and `f` lines, what load_obj_file reads, scene_loader.h:346-397);
+    coordinates with 17 significant digits so that reading them back returns the same doubles."""
+    import os
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    flat = np.asarray(tris, dtype=np.float64).reshape(-1, 3)
+    lines = ["v %s %s %s" % (repr(float(x)), repr(float(y)), repr(float(z))) for x, y, z in flat]
+    lines += ["f %d %d %d" % (3 * k + 1, 3 * k + 2, 3 * k + 3) for k in range(len(flat) // 3)]
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+STANDIN_MESHES = {"glass-of-water.yaml": glass_of_water_meshes, "coffee_machine.yaml": coffee_machine_meshes}
+
+
+def write_standin_assets(yaml_path: str, out_dir: str, detail: float = 1.0) -> str:
+    """Copies the scene file `yaml_path` (one of the reference's scenes/*.yaml) into `out_dir` and writes the
+    stand-in OBJ meshes under the relative names it refers to.  Returns the path of the copy, ready for
+    bdpt_scene_file_load / the reference's load_scene_from_yaml."""
+    import os
+    import shutil
+    name = os.path.basename(yaml_path)
+    os.makedirs(out_dir, exist_ok=True)
+    dst = os.path.join(out_dir, name)
+    shutil.copyfile(yaml_path, dst)
+    for rel, _, tris in STANDIN_MESHES[name](detail):
+        write_obj(os.path.join(out_dir, rel), tris)
+    return dst

@@ -146,6 +146,22 @@ const char* bdpt_last_error(void);
 int bdpt_context_create(int device_index, bdpt_context** out);
 int bdpt_context_destroy(bdpt_context* ctx);
 
+/* Upper limit, in bytes, of the device memory the context may take for the per-sample path state of
+ * bdpt_render / bdpt_render_device (0 restores the default: 32 GiB, at most a quarter of the free device memory).
+ * Larger batches mean fewer, longer kernel launches: a host that renders full frames at thousands of samples per
+ * pixel gains about a tenth of throughput by allowing ~170 GB of the 288 GB.  Clipped to 90 % of the free memory.
+ * No counterpart in the reference (host memory is not budgeted there). */
+int bdpt_context_set_workspace_limit(bdpt_context* ctx, uint64_t bytes);
+
+/* Which BVH walk answers bdpt_trace_closest (without counters), bdpt_trace_closest_device and bdpt_visible:
+ * the traversal kernels of the render pipeline (default; four-wide hierarchy, FP32 box tests, FP64 triangle
+ * tests) or a stackless walk over the reference's own tree in the reference's visiting order.  Both return the
+ * bits of bvh_node::hit (src/acceleration/bvh.h:50-59) / camera::visible (src/camera.h:425-438); the second
+ * exists for verification. */
+#define BDPT_WALKER_PIPELINE 0
+#define BDPT_WALKER_REFERENCE_TREE 1
+int bdpt_context_set_query_walker(bdpt_context* ctx, int walker);
+
 /* camera::initialize(), src/camera.h:160-197 (host arithmetic, glibc tan). */
 int bdpt_camera_initialize(const bdpt_camera_public* cam, bdpt_camera_state* out);
 
@@ -191,9 +207,10 @@ int bdpt_visible(bdpt_context* ctx, const bdpt_scene* scene, const double* pairs
 int bdpt_render(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam,
                 const bdpt_render_params* params, double* framebuffer, bdpt_stats* stats);
 /* Same, framebuffer in device memory; returns after enqueueing on `stream` (hipStream_t or NULL).
- * The context keeps the per-sample path state of the batches in flight in one device allocation made at the first
- * call and grown on demand: up to min(176 GB, 70 % of the free device memory) for frames large enough to use it
- * (environment: BDPT_WF_BUDGET_GB, BDPT_WF_BATCH_LOG2).  One context renders one frame at a time. */
+ * Nothing in the call waits for the device (the table of owned rows is filled by a kernel).  The context keeps
+ * the per-sample path state of the batches in flight in one device allocation made at the first call and grown on
+ * demand up to the context's workspace limit (bdpt_context_set_workspace_limit); growing it frees the previous
+ * allocation, which waits for earlier work.  One context renders one frame at a time. */
 int bdpt_render_device(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam,
                        const bdpt_render_params* params, void* d_framebuffer, void* stream);
 /* Counters of the last bdpt_render_device call that requested them (synchronises). */

@@ -30,3 +30,27 @@ def oracle():
 
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+# name of a fixture under tests/golden/ -> the scene it was made from (tests/golden/make_golden.py)
+GOLDEN_CASES = {
+    "cornell24": lambda s: s.cornell_box(48, 16, 10),
+    "cornell36": lambda s: s.cornell_box(32, 4, 10, short_box=True),
+    "showcase": lambda s: s.materials_showcase(48, 16, 8),
+    "nolight": lambda s: s.no_light_room(24, 4, 5),
+    "cornell_d1": lambda s: s.cornell_box(16, 4, 1),
+    "cornell_d2": lambda s: s.cornell_box(16, 5, 2),
+    "cornell_d12": lambda s: s.cornell_box(16, 2, 12),
+    "showcase_d20": lambda s: s.materials_showcase(24, 4, 20),
+    "showcase_defocus": lambda s: s.showcase_with_defocus(32, 16, 6),
+    # exact ties; scenes too large for the LDS copy of the whole scene; crops of the two benchmark scenes
+    "coplanar": lambda s: s.coplanar_stack(32, 16, 6),
+    "mixed3k": lambda s: s.mixed_materials_3k(40, 16, 8),
+    "glass_crop": lambda s: s.glass_of_water_standin(1920, 1080, 4, 12),
+    "coffee_crop": lambda s: s.coffee_machine_standin(1920, 1080, 4, 10),
+}
+
+
+def sha256_of(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)

@@ -89,7 +89,142 @@ def surface_pairs(hits, n, rng):
     return np.concatenate([a, b], axis=1)
 
 
-def golden_for(name, scene, tmp, *, seed, n_rays=0, n_pairs=0, crop=None, sample_crop=None, glibc=False):
+EXACT_STEPS = np.arange(-32, 33) / 16.0        # direction components with few mantissa bits: v - d and v + d are exact
+
+
+def exact_direction(rng, zeros=0):
+    """Direction whose components are multiples of 1/16 in [-2, 2]; `zeros` of them are exactly 0."""
+    while True:
+        d = rng.choice(EXACT_STEPS, 3)
+        idx = rng.permutation(3)[:zeros]
+        d[idx] = 0.0
+        if np.count_nonzero(d) == 3 - zeros:
+            return d
+
+
+def adversarial_rays(scene, node_boxes, first_rays, first_hits, n, rng):
+    """Rays aimed at the places where rounding decides what the reference's traversal returns: exactly through
+    triangle vertices and edge midpoints, exactly through corners of the boxes of bvh_node objects (a ray that only
+    touches a box), parallel to one or two axes (zero direction components: infinities and NaNs in the slab test),
+    inside the plane of axis-aligned triangles, hits at t within a few ulps of the lower bound 0.001, and upper
+    bounds within an ulp of a hit distance."""
+    verts = scene.vertex_array().reshape(-1, 3, 3)
+    lo, hi = scene_box(scene)
+    ext = hi - lo
+    hit_rows = np.flatnonzero(first_hits[:, 0] >= 0)
+    rays = []
+
+    def push(o, d, tmin=0.001, tmax=np.inf):
+        rays.append([o[0], o[1], o[2], d[0], d[1], d[2], tmin, tmax])
+
+    per = max(1, n // 8)
+    for _ in range(per):                                    # through a vertex, t = 1 there
+        v = verts[rng.integers(0, len(verts)), rng.integers(0, 3)]
+        d = exact_direction(rng, zeros=int(rng.integers(0, 2)))
+        push(v - d, d)
+    for _ in range(per):                                    # through the midpoint of an edge
+        t = verts[rng.integers(0, len(verts))]
+        k = rng.integers(0, 3)
+        m = t[k] + 0.5 * (t[(k + 1) % 3] - t[k])
+        d = exact_direction(rng)
+        push(m - d, d)
+    for _ in range(per):                                    # through a corner of a bvh_node's box
+        b = node_boxes[rng.integers(0, len(node_boxes))]
+        c = np.array([b[0 + rng.integers(0, 2)], b[2 + rng.integers(0, 2)], b[4 + rng.integers(0, 2)]])
+        if not np.isfinite(c).all():
+            continue
+        d = exact_direction(rng)
+        push(c - d, d)
+    for _ in range(per):                                    # parallel to an axis (two zero components)
+        v = verts[rng.integers(0, len(verts)), rng.integers(0, 3)]
+        o = lo + rng.uniform(0.02, 0.98, 3) * ext
+        keep = rng.integers(0, 3)                           # one coordinate of the origin lies exactly in a vertex plane
+        o[keep] = v[keep]
+        d = exact_direction(rng, zeros=2)
+        push(o, d)
+    for _ in range(per):                                    # one zero component, origin inside the scene
+        o = lo + rng.uniform(0.02, 0.98, 3) * ext
+        push(o, exact_direction(rng, zeros=1))
+    for _ in range(per):                                    # inside the plane of an axis-aligned triangle
+        for _try in range(64):
+            t = verts[rng.integers(0, len(verts))]
+            flat_axes = [a for a in range(3) if t[0, a] == t[1, a] == t[2, a]]
+            if flat_axes:
+                break
+        else:
+            break
+        a = flat_axes[0]
+        o = lo - 0.1 * ext + rng.uniform(0, 1, 3) * 1.2 * ext
+        o[a] = t[0, a]
+        d = exact_direction(rng)
+        d[a] = 0.0
+        push(o, d)
+    for _ in range(per):                                    # hit at t = 0.001 up to a few ulps
+        if len(hit_rows) == 0:
+            break
+        r = hit_rows[rng.integers(0, len(hit_rows))]
+        o, d, t0 = first_rays[r, 0:3], first_rays[r, 3:6], first_hits[r, 1]
+        push(o + (t0 - 0.001 * (1.0 + rng.integers(-6, 7) * 2.0 ** -52)) * d, d)
+    for _ in range(per):                                    # upper bound at the hit distance, one ulp below, one above
+        if len(hit_rows) == 0:
+            break
+        r = hit_rows[rng.integers(0, len(hit_rows))]
+        t0 = first_hits[r, 1]
+        tmax = [t0, np.nextafter(t0, 0.0), np.nextafter(t0, np.inf)][rng.integers(0, 3)]
+        push(first_rays[r, 0:3], first_rays[r, 3:6], 0.001, tmax)
+    return np.array(rays, dtype=np.float64)
+
+
+def adversarial_pairs(scene, hits, n, rng):
+    """Point pairs for camera::visible where rounding or an exact tie decides: far end points on axis-aligned
+    surfaces (their planes coincide with faces of bvh_node boxes), segments exactly through a vertex, end points
+    at triangle vertices and edge midpoints, both end points in one plane, and pairs closer than the 0.001 offsets."""
+    verts = scene.vertex_array().reshape(-1, 3, 3)
+    surf = hits[hits[:, 0] >= 0]
+    pts, tri = surf[:, 5:8], surf[:, 0].astype(np.int64)
+    flat = np.array([any(verts[t][0, a] == verts[t][1, a] == verts[t][2, a] for a in range(3)) for t in tri])
+    pairs = []
+    per = max(1, n // 6)
+    for _ in range(per):                                    # far end on an axis-aligned surface
+        if not flat.any():
+            break
+        b = pts[rng.choice(np.flatnonzero(flat))]
+        a = pts[rng.integers(0, len(pts))]
+        pairs.append(np.concatenate([a, b]))
+    for _ in range(per):                                    # segment exactly through a vertex of the scene
+        v = verts[rng.integers(0, len(verts)), rng.integers(0, 3)]
+        d = exact_direction(rng) * rng.choice([0.25, 1.0, 4.0])
+        pairs.append(np.concatenate([v - d, v + d]))
+    for _ in range(per):                                    # far end exactly at a vertex / an edge midpoint
+        t = verts[rng.integers(0, len(verts))]
+        k = rng.integers(0, 3)
+        b = t[k] if rng.integers(0, 2) else t[k] + 0.5 * (t[(k + 1) % 3] - t[k])
+        pairs.append(np.concatenate([pts[rng.integers(0, len(pts))], b]))
+    for _ in range(per):                                    # both end points on one axis-aligned surface plane
+        if not flat.any():
+            break
+        i = rng.choice(np.flatnonzero(flat))
+        t = verts[tri[i]]
+        a_ax = [a for a in range(3) if t[0, a] == t[1, a] == t[2, a]][0]
+        same = np.flatnonzero(pts[:, a_ax] == pts[i, a_ax])
+        pairs.append(np.concatenate([pts[i], pts[rng.choice(same)]]))
+    for _ in range(per):                                    # closer than the offsets: a == b, 0.0005, 0.002 and 0.002 + ulps apart
+        a = pts[rng.integers(0, len(pts))]
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        dist = [0.0, 0.0005, 0.002, 0.002 * (1 + 2.0 ** -50), 0.0020001][rng.integers(0, 5)]
+        pairs.append(np.concatenate([a, a + dist * d]))
+    for _ in range(per):                                    # generic surface-to-surface pairs
+        pairs.append(np.concatenate([pts[rng.integers(0, len(pts))], pts[rng.integers(0, len(pts))]]))
+    return np.array(pairs, dtype=np.float64)
+
+
+def digest(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def golden_for(name, scene, tmp, *, seed, n_rays=0, n_pairs=0, crop=None, sample_crop=None, glibc=False, n_adversarial=0,
+               tables=True):
     spath = os.path.join(tmp, name + ".scene")
     blob = scene.to_bytes()
     with open(spath, "wb") as f:
@@ -101,10 +236,17 @@ def golden_for(name, scene, tmp, *, seed, n_rays=0, n_pairs=0, crop=None, sample
     cam = rd(o("cam"))
     g["camera"] = cam
     run(HARNESS, spath, "dfs", o("leaves"), o("boxes"))
-    g["dfs_leaves"] = rd(o("leaves")).astype(np.uint32)
-    g["node_boxes"] = rd(o("boxes")).reshape(-1, 6)
+    node_boxes = rd(o("boxes")).reshape(-1, 6)
     run(HARNESS, spath, "triangles", o("tris"))
-    g["triangle_data"] = rd(o("tris")).reshape(-1, 16)
+    if tables:
+        g["dfs_leaves"] = rd(o("leaves")).astype(np.uint32)
+        g["node_boxes"] = node_boxes
+        g["triangle_data"] = rd(o("tris")).reshape(-1, 16)
+    else:       # large scene: SHA-256 of the tables (uint32 leaf ids, float64 boxes, float64 triangle data)
+        g["dfs_leaves_sha256"] = digest(rd(o("leaves")).astype(np.uint32))
+        g["node_boxes_sha256"] = digest(node_boxes)
+        g["triangle_data_sha256"] = digest(rd(o("tris")))
+        g["n_nodes"] = np.array([len(node_boxes)], dtype=np.int64)
 
     rng = np.random.default_rng(seed)
     if n_rays:
@@ -120,6 +262,17 @@ def golden_for(name, scene, tmp, *, seed, n_rays=0, n_pairs=0, crop=None, sample
             run(HARNESS, spath, "visible", o("pairs"), o("vis"))
             g["pairs"] = pairs
             g["visible"] = rd(o("vis")).astype(np.uint8)
+        if n_adversarial:
+            adv = adversarial_rays(scene, node_boxes, rays, g["hits"], n_adversarial, rng)
+            adv.tofile(o("arays"))
+            run(HARNESS, spath, "hits", o("arays"), o("ahits"))
+            g["adv_rays"] = adv
+            g["adv_hits"] = rd(o("ahits")).reshape(-1, 11)
+            apairs = adversarial_pairs(scene, g["hits"], n_adversarial, rng)
+            apairs.tofile(o("apairs"))
+            run(HARNESS, spath, "visible", o("apairs"), o("avis"))
+            g["adv_pairs"] = apairs
+            g["adv_visible"] = rd(o("avis")).astype(np.uint8)
 
     W = scene.camera.image_width
     H = int(cam[12])
@@ -138,7 +291,9 @@ def golden_for(name, scene, tmp, *, seed, n_rays=0, n_pairs=0, crop=None, sample
         run(HARNESS_GLIBC, spath, "render", seed, x0, y0, x1, y1, o("fbg"))
         g["framebuffer_glibc_libm"] = rd(o("fbg")).reshape(y1 - y0, x1 - x0, 3)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **g)
-    print(name, "ok:", scene.n_triangles, "triangles,", len(g["node_boxes"]), "nodes")
+    print(name, "ok:", scene.n_triangles, "triangles,", len(node_boxes), "nodes",
+          ("| adversarial: %d rays (%d hit), %d pairs (%d visible)" % (len(g["adv_rays"]), (g["adv_hits"][:, 0] >= 0).sum(),
+                                                                      len(g["adv_pairs"]), g["adv_visible"].sum())) if n_adversarial else "")
     return g, spath
 
 
@@ -167,6 +322,20 @@ def unidirectional_fixtures(tmp):
     golden_unidirectional("uni_cornell_d1", scenes.cornell_box(16, 4, 1), tmp, seed=2)
 
 
+def new_fixtures(tmp):
+    """Scenes whose tables do not fit the LDS copy (the traversal kernels read them from global memory), and geometry
+    made of exact ties."""
+    golden_for("coplanar", scenes.coplanar_stack(32, 16, 6), tmp, seed=21, n_rays=2048, n_pairs=1024, n_adversarial=4096,
+               sample_crop=(8, 8, 24, 24))
+    golden_for("mixed3k", scenes.mixed_materials_3k(40, 16, 8), tmp, seed=17, n_rays=4096, n_pairs=2048, n_adversarial=4096,
+               sample_crop=(12, 12, 28, 28))
+    # a crop of the benchmark scene itself (55 k triangles): the middle of the glass, 4 spp, depth 12
+    golden_for("glass_crop", scenes.glass_of_water_standin(1920, 1080, 4, 12), tmp, seed=0, n_rays=4096, n_pairs=2048,
+               n_adversarial=2048, crop=(944, 520, 976, 536), tables=False)
+    golden_for("coffee_crop", scenes.coffee_machine_standin(1920, 1080, 4, 10), tmp, seed=0, n_rays=4096, n_pairs=2048,
+               n_adversarial=2048, crop=(900, 560, 932, 576), tables=False)
+
+
 def main():
     for b in (HARNESS, HARNESS_GLIBC, HARNESS_NOSHIM):
         if not os.path.exists(b):
@@ -174,6 +343,10 @@ def main():
     if "--only-defocus" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
             golden_for("showcase_defocus", scenes.showcase_with_defocus(32, 16, 6), tmp, seed=13, sample_crop=(8, 8, 24, 24))
+        return
+    if "--only-new" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            new_fixtures(tmp)
         return
     if "--only-unidirectional" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
@@ -183,7 +356,7 @@ def main():
         unidirectional_fixtures(tmp)
         # config-2 geometry, small image
         g, spath = golden_for("cornell24", scenes.cornell_box(48, 16, 10), tmp, seed=0, n_rays=2048, n_pairs=1024,
-                              sample_crop=(20, 20, 28, 28), glibc=True)
+                              sample_crop=(20, 20, 28, 28), glibc=True, n_adversarial=4096)
         # colors_to_rgb8 on that framebuffer (src/image/wpng.h:14-35)
         fb = g["framebuffer"]
         fb.tofile(os.path.join(tmp, "fb.bin"))
@@ -202,6 +375,8 @@ def main():
         golden_for("showcase_d20", scenes.materials_showcase(24, 4, 20), tmp, seed=9, sample_crop=(0, 0, 24, 16))
         # thin-lens camera (defocus_angle > 0)
         golden_for("showcase_defocus", scenes.showcase_with_defocus(32, 16, 6), tmp, seed=13, sample_crop=(8, 8, 24, 24))
+
+        new_fixtures(tmp)
 
         # the unshimmed reference (real src/main.h: one serial default-seeded mt19937)
         sc = scenes.cornell_box(16, 4, 5)

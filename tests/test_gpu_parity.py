@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import GOLDEN_CASES, load_golden, sha256_of
 
 pytestmark = pytest.mark.gpu
 
@@ -35,17 +35,7 @@ def ctx():
     c.close()
 
 
-CASES = {
-    "cornell24": lambda s: s.cornell_box(48, 16, 10),
-    "cornell36": lambda s: s.cornell_box(32, 4, 10, short_box=True),
-    "showcase": lambda s: s.materials_showcase(48, 16, 8),
-    "nolight": lambda s: s.no_light_room(24, 4, 5),
-    "cornell_d1": lambda s: s.cornell_box(16, 4, 1),
-    "cornell_d2": lambda s: s.cornell_box(16, 5, 2),
-    "cornell_d12": lambda s: s.cornell_box(16, 2, 12),
-    "showcase_d20": lambda s: s.materials_showcase(24, 4, 20),
-    "showcase_defocus": lambda s: s.showcase_with_defocus(32, 16, 6),
-}
+CASES = GOLDEN_CASES
 
 
 @pytest.fixture(scope="module", params=sorted(CASES))
@@ -95,10 +85,16 @@ def test_device_random_stream_matches_oracle(ctx, oracle):
 # ------------------------------------------------------------------ BVH build (host) and traversal (device)
 def test_bvh_matches_reference(case):
     name, flat, sc, g = case
-    assert np.array_equal(sc.dfs_leaves(), g["dfs_leaves"])
-    assert_bit_equal(sc.node_boxes(), g["node_boxes"], "node boxes")
     info = sc.info()
-    assert info.n_nodes == len(g["node_boxes"]) and info.n_triangles == flat.n_triangles
+    assert info.n_triangles == flat.n_triangles
+    if "dfs_leaves" in g:
+        assert np.array_equal(sc.dfs_leaves(), g["dfs_leaves"])
+        assert_bit_equal(sc.node_boxes(), g["node_boxes"], "node boxes")
+        assert info.n_nodes == len(g["node_boxes"])
+    else:       # large scene: the fixture holds the SHA-256 of the tables
+        assert np.array_equal(sha256_of(sc.dfs_leaves().astype(np.uint32)), g["dfs_leaves_sha256"])
+        assert np.array_equal(sha256_of(sc.node_boxes()), g["node_boxes_sha256"])
+        assert info.n_nodes == int(g["n_nodes"][0])
 
 
 def test_closest_hits_match_reference(case):
@@ -109,15 +105,45 @@ def test_closest_hits_match_reference(case):
     assert_bit_equal(hits, g["hits"], "hit records (triangle id, t, u, v, front_face, p, normal)")
     got = [st.rays_traced, st.aabb_tests, st.aabb_hits, st.bvh_node_visits, st.triangle_tests, st.triangle_hits]
     assert got[1:] == [int(v) for v in g["hits_stats"][1:6]], "BvhStats counters of the traversal"
-    # the counter-free kernel variant returns the same records
-    assert_bit_equal(sc.trace_closest(g["rays"]), g["hits"], "hit records, no-stats kernel")
+    # without counters the query runs through the traversal kernel of the render pipeline (four-wide hierarchy)
+    assert_bit_equal(sc.trace_closest(g["rays"]), g["hits"], "hit records, pipeline traversal kernel")
+    # ... or, on request, through the counter-free variant of the walk over the reference's tree
+    sc.ctx.set_query_walker(capi.WALKER_REFERENCE_TREE)
+    try:
+        assert_bit_equal(sc.trace_closest(g["rays"]), g["hits"], "hit records, reference-tree walk without counters")
+    finally:
+        sc.ctx.set_query_walker(capi.WALKER_PIPELINE)
 
 
 def test_visible_matches_reference(case):
     name, flat, sc, g = case
     if "pairs" not in g:
         pytest.skip("no visibility fixture")
-    assert np.array_equal(sc.visible(g["pairs"]), g["visible"])
+    assert np.array_equal(sc.visible(g["pairs"]), g["visible"]), "pipeline visibility kernel"
+    sc.ctx.set_query_walker(capi.WALKER_REFERENCE_TREE)
+    try:
+        assert np.array_equal(sc.visible(g["pairs"]), g["visible"]), "reference-tree walk"
+    finally:
+        sc.ctx.set_query_walker(capi.WALKER_PIPELINE)
+
+
+@pytest.mark.parametrize("walker", ["pipeline", "reference_tree"])
+def test_adversarial_rays_and_pairs(case, walker):
+    """The places where rounding or an exact tie decides what the reference returns (rays through vertices, edge
+    midpoints and corners of bvh_node boxes, axis-parallel and in-plane rays, t at 0.001, upper bounds at the hit
+    distance; pairs with end points on box faces, at vertices, in one plane, closer than the offsets), through the
+    traversal kernels of the render pipeline and through the walk over the reference's tree."""
+    name, flat, sc, g = case
+    if "adv_rays" not in g:
+        pytest.skip("no adversarial fixture")
+    sc.ctx.set_query_walker(capi.WALKER_PIPELINE if walker == "pipeline" else capi.WALKER_REFERENCE_TREE)
+    try:
+        assert_bit_equal(sc.trace_closest(g["adv_rays"]), g["adv_hits"], "adversarial hit records")
+        got = sc.visible(g["adv_pairs"])
+        bad = np.flatnonzero(got != g["adv_visible"])
+        assert len(bad) == 0, "%d of %d adversarial pairs differ, first %d: %r" % (len(bad), len(got), bad[0], g["adv_pairs"][bad[0]])
+    finally:
+        sc.ctx.set_query_walker(capi.WALKER_PIPELINE)
 
 
 def test_empty_inputs(case):
@@ -386,12 +412,16 @@ def test_image_does_not_depend_on_launch_settings(scenes, ctx, lds_scene, monkey
     cam = capi.camera_initialize(flat.camera)
     want = sc.render(cam, seed=11)
     assert want.max() > 0
+    sc.close()
     for setting in WF_SETTINGS:
         with monkeypatch.context() as m:
             for k, v in setting.items():
                 m.setenv(k, v)
-            assert_bit_equal(sc.render(cam, seed=11), want, str(setting))
-    sc.close()
+            c2 = capi.Context(0)              # the settings are read when a context is created
+            sc2 = c2.scene(flat)
+            assert_bit_equal(sc2.render(cam, seed=11), want, str(setting))
+            sc2.close()
+            c2.close()
 
 
 def test_bad_arguments_are_rejected(scenes, ctx):

@@ -184,3 +184,42 @@ def test_yaml_reader_agrees_with_pyyaml(text):
 def test_yaml_reader_rejects_what_it_does_not_support(text):
     with pytest.raises(capi.BdptError):
         capi.yaml_to_json(text)
+
+
+def _with_benchmark_overrides(flat, twin):
+    """The benchmark configurations override resolution, samples and depth of the YAML's camera block."""
+    c, t = flat.camera, twin.camera
+    c.image_width, c.aspect_ratio, c.samples_per_pixel, c.max_depth = t.image_width, t.aspect_ratio, t.samples_per_pixel, t.max_depth
+    return flat
+
+
+@pytest.mark.parametrize("name,builder,args", [("glass-of-water.yaml", "glass_of_water_standin", (1920, 1080, 1024, 12)),
+                                               ("coffee_machine.yaml", "coffee_machine_standin", (1920, 1080, 512, 10))])
+def test_reference_scene_files_load_unchanged(tmp_path, name, builder, args):
+    """The reference's own scenes/*.yaml (tests/data/scenes, byte for byte) through bdpt_scene_file_load, with the
+    stand-in OBJ meshes written under the file names the YAML refers to: the flat scene is exactly the one the
+    Python builder assembles (the one the benchmarks and the full-size tests use), and the Python restatement of the
+    loader agrees."""
+    scenes = importlib.import_module("bidirectional-path-tracer_amd.scenes")
+    path = scenes.write_standin_assets(os.path.join(DATA, "scenes", name), str(tmp_path), detail=0.25)
+    flat = capi.load_scene_file(path)
+    ref = slo.load_scene(path)
+    assert_same_scene(flat, ref)
+    twin = getattr(scenes, builder)(*args, detail=0.25)
+    # the camera block of the file: resolution / samples / depth are the file's (or the reference's defaults)
+    if name == "glass-of-water.yaml":
+        assert (flat.camera.image_width, flat.camera.samples_per_pixel, flat.camera.max_depth) == (1280, 400, 80)
+        assert flat.camera.aspect_ratio == 1280 / 720 and flat.camera.file_name == "glass_of_water.png"
+    else:
+        assert (flat.camera.image_width, flat.camera.samples_per_pixel, flat.camera.max_depth) == (800, 50, 10)
+        assert flat.camera.aspect_ratio == 1.0 and flat.camera.file_name == "image.png"
+    flat.camera.file_name = twin.camera.file_name
+    _with_benchmark_overrides(flat, twin)
+    assert flat.to_bytes() == twin.to_bytes()
+    assert flat.lights == twin.lights and [m.type for m in flat.materials] == [m.type for m in twin.materials]
+
+
+def test_reference_scene_file_without_its_meshes_fails_like_the_reference(tmp_path):
+    shutil.copyfile(os.path.join(DATA, "scenes", "coffee_machine.yaml"), tmp_path / "coffee_machine.yaml")
+    with pytest.raises(capi.BdptError, match="Failed to open OBJ file"):
+        capi.load_scene_file(str(tmp_path / "coffee_machine.yaml"))
