@@ -88,7 +88,7 @@ struct SceneDev {
     const uint32_t* sleaf;          // per entry of `stris`: the node of `nodes` that holds the triangle
     const GpuQuadNode* xnodes;      // closest-hit hierarchy (surface-area heuristic, four children, FP32 boxes)
     const GpuTri* xtris;            // its triangles in its own leaf order; `pad` = position in `stris`; `material` holds
-                                    // the bits of an FP32 number instead: the triangle's grazing threshold (wavefront.hip)
+                                    // the high 32 bits of a double instead: the triangle's grazing threshold (wavefront.hip)
     uint32_t n_xnodes;
     const GpuTriAux* aux;
     const GpuMaterial* mats;

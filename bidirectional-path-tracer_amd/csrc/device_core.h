@@ -161,25 +161,25 @@ BDPT_DEV bool tri_test(const GpuTri& tr, V3 o, V3 d, double tmin, double tmax, d
     return true;
 }
 
-// The same test without the upper end of the interval: true when everything but `t <= tmax` holds; also returns
-// the determinant.  (tri_test(..., tmax) == tri_candidate(...) && t <= tmax, bit for bit.)
-BDPT_DEV bool tri_candidate(const GpuTri& tr, V3 o, V3 d, double tmin, double& t_out, double& u_out, double& v_out,
-                            double& det_out) {
-    V3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
-    V3 pvec = cross(d, e2);
-    double det = dot(e1, pvec);
-    if (__builtin_fabs(det) < 1e-8) return false;
-    double inv_det = 1.0 / det;
-    V3 tvec = sub(o, ld3(tr.v0));
-    double u = dot(tvec, pvec) * inv_det;
-    if (u < 0.0 || u > 1.0) return false;
-    V3 qvec = cross(tvec, e1);
-    double v = dot(d, qvec) * inv_det;
-    if (v < 0.0 || u + v > 1.0) return false;
-    double t = dot(e2, qvec) * inv_det;
-    if (!(tmin <= t)) return false;
-    t_out = t; u_out = u; v_out = v; det_out = det;
-    return true;
+// The same arithmetic as straight-line code for the traversal kernels: every lane of a wave evaluates the whole test
+// (in a wave some lane almost always gets to the end, so the early exits above only cost branches and delay the
+// loads of the later operands) and the outcome is one predicate.  Each of t, u, v, det is formed by the operations
+// of triangle::hit in their order, so a lane for which tri_test returns true gets the same bits here; the upper end
+// of the interval is left to the caller:  tri_test(..., tmax) == tri_candidate(...) && t <= tmax.
+BDPT_DEV bool tri_candidate(const GpuTri& tr, V3 o, V3 d, double tmin, double& t, double& u, double& v, double& det) {
+    const V3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+    const V3 pvec = cross(d, e2);
+    det = dot(e1, pvec);
+    const double inv_det = 1.0 / det;
+    const V3 tvec = sub(o, ld3(tr.v0));
+    u = dot(tvec, pvec) * inv_det;
+    const V3 qvec = cross(tvec, e1);
+    v = dot(d, qvec) * inv_det;
+    t = dot(e2, qvec) * inv_det;
+    // (negated comparisons as in the reference: a NaN fails where the reference's test lets it pass and vice versa)
+    const unsigned ok = (unsigned)!(__builtin_fabs(det) < 1e-8) & (unsigned)!(u < 0.0) & (unsigned)!(u > 1.0) & (unsigned)!(v < 0.0) &
+                        (unsigned)!(u + v > 1.0) & (unsigned)(tmin <= t);
+    return ok != 0u;
 }
 
 // bvh_node::hit (src/acceleration/bvh.h:50-59) + aabb::hit (src/acceleration/aabb.h:41-66) as a walk

@@ -474,8 +474,8 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
         out.coord_bound = (double)round_up(out.coord_bound * 1.0000002);     // covers the outward FP32 rounding of the boxes
         // Hits the traversal kernels re-check against the reference's own tree (wavefront.hip, "exact ties"): a hit
         // within bary_margin of the triangle's outline, or by a ray within 1e-4 rad of the triangle's plane
-        // (|det| = |d . (e1 x e2)| below 1e-4 |d| |e1 x e2|; the threshold without the |d| is kept per triangle, as
-        // FP32 bits in the otherwise unused material field).  The margin argument needs a hit inside the outline
+        // (|det| = |d . (e1 x e2)| below 1e-4 |d| |e1 x e2|; the threshold without the |d| is kept per triangle: the
+        // high 32 bits of that double, in the otherwise unused material field).  The margin argument needs a hit inside the outline
         // to be at least ~64 ulp of the coordinates inside the triangle's box on every axis the box is not thin
         // (< 1e-4, where the reference pads) on: bary_margin * 1e-4 >= 64 ulp(4 * coord_bound).  A triangle whose
         // box is thin on two axes has no such axis pair and is always re-checked (threshold +infinity).
@@ -487,10 +487,11 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
             t.pad = (int32_t)sb.leaf_order[k];
             int thin_axes = 0;
             for (int a = 0; a < 3; a++) thin_axes += (btris[id].box.hi[a] - btris[id].box.lo[a] < 1e-4) ? 1 : 0;
-            float graze = round_up(1e-4 * 2.0 * out.aux[id].area);       // |e1 x e2| = 2 area
-            if (thin_axes >= 2) graze = std::numeric_limits<float>::infinity();
-            static_assert(sizeof(float) == sizeof(int32_t), "FP32 bits in an int32 field");
-            std::memcpy(&t.material, &graze, sizeof graze);
+            double graze = 1e-4 * 2.0 * out.aux[id].area;                // |e1 x e2| = 2 area
+            if (thin_axes >= 2 || !(graze == graze)) graze = std::numeric_limits<double>::infinity();
+            uint64_t bits;
+            std::memcpy(&bits, &graze, sizeof bits);
+            t.material = (int32_t)(uint32_t)(bits >> 32) + 1;            // high word, rounded up
             out.xtris[k] = t;
         }
     }

@@ -146,8 +146,8 @@ __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb,
 // almost inside the triangle's plane (u, v and t then carry a large rounding error), a hit at the lower end 0.001 of
 // the interval, or two hits at the same distance (coplanar surfaces: the second one's boxes are tested against an
 // interval that ends exactly where they begin, and rounding decides whether the reference ever tests it).  Such
-// hits are recognised by cheap sufficient conditions (grazes(), and a relative distance below 1e-9 between a hit
-// and the running closest distance).  A visibility ray then asks reference_reaches(); a closest-hit ray gives up
+// hits are recognised by cheap sufficient conditions (grazes(), and nearly_equal() distances of a hit and the
+// running closest distance).  A visibility ray then asks reference_reaches(); a closest-hit ray gives up
 // the walk and is marked kHitRedo: the kernel that reads the hit next (k_shade, k_hits_out) repeats the query with
 // the reference's own traversal (device_core.h: walk) for it.  About one ray in 10^5 takes that road.
 // Why the remaining hits are safe: the hit point p is inside the triangle by at least bary_margin in every
@@ -157,15 +157,39 @@ __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb,
 // axes are always re-checked), so the ray still runs inside that box on one side of p.  The slab arithmetic of
 // aabb.h:41-66 is accurate to a few ulp of the coordinates, far below those margins, and the interval it is
 // clipped to, [0.001, closest so far], contains t with the same margins unless one of the conditions above holds.
-constexpr double kTieRelative = 1e-9;
-
-// the triangle's grazing threshold (1e-4 |e1 x e2|, or +infinity for a triangle that is always re-checked) travels
-// as FP32 bits in the `material` field of the traversal hierarchy's triangle table
-BDPT_DEV bool grazes(const GpuTri& tr, double u, double v, double t, double det, double bary_margin, float ray_len) {
-    const float threshold = __int_as_float(tr.material);
-    return u < bary_margin || v < bary_margin || u + v > 1.0 - bary_margin || t < 0.001 + 1e-9 ||
-           __builtin_fabsf((float)det) < threshold * ray_len;
+// The conditions are evaluated on the HIGH 32 bits of the numbers (sign, exponent, 20 mantissa bits): for
+// non-negative doubles the bit patterns order like the values, so "x < c" implies hi(x) <= hi(c), and every test
+// below is an integer compare that holds whenever the exact condition holds (a superset; a few more rays than
+// necessary take the slow road).  Distances within 2^-19 of each other count as equal.
+BDPT_DEV uint32_t hi32(double x) { return (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32); }
+struct GrazeBits {
+    uint32_t bary_low;      // hi(bary_margin) + 1:       u or v below the margin      <=>  hi(u) < bary_low
+    uint32_t bary_high;     // hi(1 - bary_margin):       u + v above 1 - margin       <=>  hi(u + v) >= bary_high
+    uint32_t t_low;         // hi(0.001 + 1e-9) + 1:      t at the lower end            <=>  hi(t) < t_low
+    uint32_t len_offset;    // hi(ray length bound) - hi(1.0) + one binade: added to the triangle's threshold bits.  The
+                            // sum of two high words underestimates the high word of the product by less than a
+                            // factor 4/3, which the extra binade (a factor 2) covers.
+};
+BDPT_DEV GrazeBits graze_bits(double bary_margin, float ray_len) {
+    GrazeBits g;
+    g.bary_low = hi32(bary_margin) + 1u;
+    g.bary_high = hi32(1.0 - bary_margin);
+    g.t_low = hi32(0.001 + 1e-9) + 1u;
+    const uint32_t len_hi = hi32((double)ray_len);
+    // (a NaN or infinite bound: every hit is re-checked)
+    g.len_offset = (len_hi >= 0x7FF00000u) ? 0x7FF00000u : (len_hi > 0x3FF00000u ? len_hi - 0x3FF00000u : 0u) + 0x00100000u;
+    return g;
 }
+// the triangle's grazing threshold - the high word of the double 1e-4 |e1 x e2|, or of +infinity for a triangle that
+// is always re-checked - travels in the `material` field of the traversal hierarchy's triangle table
+BDPT_DEV bool grazes(const GpuTri& tr, double u, double v, double t, double det, const GrazeBits& g) {
+    const uint32_t limit = (uint32_t)tr.material + g.len_offset;
+    // (bitwise, not short-circuit: five compares and four ORs without a branch)
+    return ((unsigned)((hi32(u) & 0x7FFFFFFFu) < g.bary_low) | (unsigned)((hi32(v) & 0x7FFFFFFFu) < g.bary_low) |
+            (unsigned)(hi32(u + v) >= g.bary_high) | (unsigned)(hi32(t) < g.t_low) | (unsigned)((hi32(det) & 0x7FFFFFFFu) < limit)) != 0u;
+}
+// |hi(a) - hi(b)| <= 1 for positive a, b (+infinity included)
+BDPT_DEV bool nearly_equal(double a, double b) { return (hi32(a) - hi32(b) + 1u) <= 2u; }
 
 constexpr int kQuadStackDepth = kQuadStackEntries;
 constexpr int32_t kPop = (int32_t)0x80000000;   // neither an interior index (>= 0) nor a leaf reference
@@ -311,9 +335,8 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                              const int kLeafThreshold, const int kLeafInner, const double coord_bound, double* lds_stack, const int kLdsStack,
                              const uint32_t first_base) {
     const float bound_f32 = float_up(coord_bound);
-    const double bary_margin = sc.bary_margin;
     // upper bound of |d| over the rays of this launch (visibility rays have unit directions)
-    const float ray_len = SHADOW ? 1.0001f : (wb.ray_len_ptr ? *wb.ray_len_ptr : wb.ray_len);
+    const GrazeBits gbits = graze_bits(sc.bary_margin, SHADOW ? 1.0001f : (wb.ray_len_ptr ? *wb.ray_len_ptr : wb.ray_len));
     bool redo = false;                  // closest-hit rays: the walk met an exact tie, see above
     bool has = false;
     uint32_t slot = 0;
@@ -347,6 +370,9 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
     if (first_base < count) { pool_next = first_base; pool_end = (first_base + kChunk < count) ? first_base + kChunk : count; }
     bool exhausted = (pool_next == pool_end);
     uint32_t n_records = 0, n_box_hits = 0, n_tri = 0, n_tri_hits = 0, n_rays = 0;
+#ifdef BDPT_AB_COUNT_REDO
+    uint32_t n_redo = 0;
+#endif
 
     for (;;) {
         const unsigned long long idle = __ballot(!has);
@@ -458,19 +484,18 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                         // accepted triangle contain the hit point with a margin, so they pass; a hit at the far end
                         // (the far end point's own surface, t = max_t up to rounding: most unoccluded pairs) or a
                         // grazing one counts only if the reference's own boxes let it through.
-                        const bool check = (closest - t <= 1e-9 * closest + 1e-12) || grazes(tr, u, v, t, det, bary_margin, ray_len);
+                        const bool check = nearly_equal(t, closest) || grazes(tr, u, v, t, det, gbits);
                         if (!check || reference_reaches(sc, sc.sleaf[tr.pad], o, d, closest)) { h.tri = tr.pad; done = true; leaf_left = 0; }
                     }
-                } else if (cand) {
-                    const bool tie = __builtin_fabs(t - closest) <= kTieRelative * t;        // (false while closest is +infinity)
-                    if (inside || tie) {
-                        if (tie || grazes(tr, u, v, t, det, bary_margin, ray_len)) { redo = true; done = true; leaf_left = 0; }
-                        // equal t: the reference keeps the triangle it visits later = larger position in
-                        // its leaf order (tr.pad)
-                        else if (t < closest || h.tri < 0 || tr.pad > h.tri) {
-                            closest = t; h.tri = tr.pad;           // the hit distance IS the running bound
-                        }
-                    }
+                } else {
+                    // (the walk goes on after an exact tie: rare, and the loop keeps its shape - no branch here)
+                    const unsigned tied = (unsigned)cand & ((unsigned)nearly_equal(t, closest) | ((unsigned)inside & (unsigned)grazes(tr, u, v, t, det, gbits)));
+                    redo = ((unsigned)redo | tied) != 0u;
+                    // equal t: the reference keeps the triangle it visits later = larger position in
+                    // its leaf order (tr.pad)
+                    const bool better = ((unsigned)inside & ((unsigned)(t < closest) | (unsigned)(h.tri < 0) | (unsigned)(tr.pad > h.tri))) != 0u;
+                    closest = better ? t : closest;           // the hit distance IS the running bound
+                    h.tri = better ? tr.pad : h.tri;
                 }
                 if (leaf_left == 0 && !done) pop = true;
             }
@@ -503,6 +528,9 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
                     atomicOr(&wb.vis[(uint64_t)(bidx >> 6) * wb.ns + s], 1ull << (bidx & 63u));
                 }
             } else {
+#ifdef BDPT_AB_COUNT_REDO
+                if (STATS && redo) n_redo++;
+#endif
                 wb.hit_tri[slot] = redo ? kHitRedo : h.tri;      // position in the reference's leaf order (k_shade turns it into the triangle id)
                 // the barycentric coordinates of the hit are not kept: nothing on this path reads them (the
                 // reference's hit_record carries u, v for textures, and every texture here is a solid colour)
@@ -517,7 +545,11 @@ BDPT_DEV void traverse_queue(const Mem& mem, const SceneDev& sc, const WfBuffers
         flush_wave_counter(&stats[2], n_box_hits);
         flush_wave_counter(&stats[3], 2ull * n_records);   // in units of 64 bytes fetched (both record types are 128 bytes)
         flush_wave_counter(&stats[4], n_tri);
+#ifdef BDPT_AB_COUNT_REDO
+        flush_wave_counter(&stats[5], n_redo);
+#else
         flush_wave_counter(&stats[5], n_tri_hits);
+#endif
     }
 }
 
