@@ -85,6 +85,7 @@ EXPORTED_SYMBOLS = [
     "bdpt_colors_to_rgb8", "bdpt_colors_to_rgb8_device", "bdpt_device_sincos", "bdpt_device_random_doubles",
     "bdpt_device_arith", "bdpt_scene_file_load", "bdpt_scene_file_destroy", "bdpt_scene_file_get", "bdpt_write_png", "bdpt_debug_yaml_to_json",
     "bdpt_reduce_framebuffer", "bdpt_context_set_workspace_limit", "bdpt_context_set_query_walker",
+    "bdpt_render_device_static",
 ]
 
 WALKER_PIPELINE = 0          # traversal kernels of the render pipeline (default)
@@ -124,6 +125,7 @@ def load_library() -> C.CDLL:
     lib.bdpt_visible.argtypes = [vp, vp, vp, u64, vp]
     lib.bdpt_render.argtypes = [vp, vp, C.POINTER(CameraState), C.POINTER(RenderParams), vp, C.POINTER(Stats)]
     lib.bdpt_render_device.argtypes = [vp, vp, C.POINTER(CameraState), C.POINTER(RenderParams), vp, vp]
+    lib.bdpt_render_device_static.argtypes = [vp, vp, C.POINTER(CameraState), C.POINTER(RenderParams), vp, vp]
     lib.bdpt_render_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.bdpt_render_get_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.bdpt_render_get_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -381,6 +383,18 @@ class Scene:
         p.flags = self._flags(want_stats, time_kernel, megakernel, time_stages)
         _check(self.lib.bdpt_render_device(self.ctx.h, self.h, C.byref(cam_state), C.byref(p), C.c_void_p(d_framebuffer),
                                            C.c_void_p(stream)))
+
+    def render_device_static(self, cam_state: CameraState, d_framebuffer: int, seed=0, rect=None, shard=(0, 1, 1),
+                             want_stats=False, stream: int = 0, time_kernel=False):
+        """bdpt_render_device_static: the same render out of the library's static workspace, allocating nothing."""
+        p = RenderParams()
+        p.seed = seed
+        if rect is not None:
+            p.x0, p.y0, p.x1, p.y1 = [int(v) for v in rect]
+        p.shard_index, p.shard_count, p.shard_rows = shard
+        p.flags = self._flags(want_stats, time_kernel)
+        _check(self.lib.bdpt_render_device_static(self.ctx.h, self.h, C.byref(cam_state), C.byref(p), C.c_void_p(d_framebuffer),
+                                                  C.c_void_p(stream)))
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

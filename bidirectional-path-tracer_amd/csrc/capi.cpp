@@ -15,6 +15,7 @@
 #include "bdpt_types.h"
 #include "kernels.h"
 #include "scene_build.h"
+#include "static_scratch.h"
 #include "wavefront.h"
 
 using namespace bdpt;
@@ -90,6 +91,9 @@ struct bdpt_context {
     Knobs knobs{};
     size_t workspace_limit = 0;          // bytes; 0 = default (kDefaultWorkspaceLimit, at most a quarter of the free memory)
     int query_walker = BDPT_WALKER_PIPELINE;
+    // this GPU's copy of the library's static workspace (bdpt_render_device_static), looked up when the context is made
+    void* static_ws = nullptr;
+    hipError_t static_ws_status = hipErrorNotInitialized;
     // workspace of the ray / visibility query entry points
     void* query_ws = nullptr;
     size_t query_ws_bytes = 0;
@@ -632,6 +636,8 @@ int bdpt_context_create(int device_index, bdpt_context** out) {
     ctx->device = device_index;
     ctx->cu_count = prop.multiProcessorCount;
     ctx->knobs = read_knobs();
+    // `device_index` is the current device here (guard above): the address of the static workspace on THIS GPU
+    ctx->static_ws_status = static_scratch_address(device_index, &ctx->static_ws);
     if (hipMalloc(&ctx->unit_counter, 256) != hipSuccess || hipMalloc(&ctx->stats, 256) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming) != hipSuccess) {
@@ -885,6 +891,16 @@ int bdpt_render_device(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_ca
     if (!ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "null context");
     DeviceGuard guard(ctx->device);
     return render_impl(ctx, scene, cam, params, static_cast<double*>(d_framebuffer), static_cast<hipStream_t>(stream));
+}
+
+int bdpt_render_device_static(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam,
+                              const bdpt_render_params* params, void* d_framebuffer, void* stream) {
+    if (!ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "null context");
+    if (ctx->static_ws_status != hipSuccess || !ctx->static_ws)
+        return fail(BDPT_ERR_DEVICE, std::string("the static workspace of this GPU could not be located: ") + hipGetErrorString(ctx->static_ws_status));
+    DeviceGuard guard(ctx->device);
+    return render_impl(ctx, scene, cam, params, static_cast<double*>(d_framebuffer), static_cast<hipStream_t>(stream),
+                       ctx->static_ws, kStaticScratchBytes);
 }
 
 int bdpt_render_get_stats(bdpt_context* ctx, bdpt_stats* out) {
