@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbdpt_amd.so")
+LIB_PATH = os.environ.get("BDPT_LIB") or os.path.join(_HERE, "libbdpt_amd.so")     # (BDPT_LIB: another build of the same library, for A/B timing)
 
 BDPT_RENDER_COUNT_STATS = 1     # counters with the reference's BvhStats semantics
 BDPT_RENDER_COUNT_WORK = 2      # counters of the work the production path does

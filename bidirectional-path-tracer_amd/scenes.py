@@ -113,6 +113,29 @@ class FlatScene:
         return b"".join(out)
 
 
+def flat_scene_from_bytes(blob: bytes) -> FlatScene:
+    """Inverse of FlatScene.to_bytes (layout: oracle/flat_scene.h)."""
+    if blob[:8] != b"BDPTSCN1":
+        raise ValueError("not a flat scene file")
+    n_mat, n_tri, n_light, _ = struct.unpack_from("<4I", blob, 8)
+    off = 24
+    s = FlatScene()
+    for _ in range(n_mat):
+        t, _pad, r, g, b, fuzz, ior = struct.unpack_from("<2i5d", blob, off)
+        s.materials.append(Material(t, (r, g, b), fuzz, ior))
+        off += 48
+    rec = np.frombuffer(blob, dtype=[("v", "<f8", 9), ("m", "<i4"), ("pad", "<i4")], count=n_tri, offset=off)
+    s.vertices = _Rows(rec["v"].copy())
+    s.tri_material = rec["m"].astype(np.int64).tolist()
+    off += 80 * n_tri
+    s.lights = list(struct.unpack_from("<%dI" % n_light, blob, off))
+    off += 4 * (n_light + (n_light % 2))
+    c = struct.unpack_from("<16d4i", blob, off)
+    s.camera = Camera(lookfrom=c[0:3], lookat=c[3:6], vup=c[6:9], vfov=c[9], aspect_ratio=c[10], focus_dist=c[11],
+                      defocus_angle=c[12], background=c[13:16], image_width=c[16], samples_per_pixel=c[17], max_depth=c[18])
+    return s
+
+
 def _add(a, b):
     return (a[0] + b[0], a[1] + b[1], a[2] + b[2])
 

@@ -48,6 +48,8 @@ GOLDEN_CASES = {
     "mixed3k": lambda s: s.mixed_materials_3k(40, 16, 8),
     "glass_crop": lambda s: s.glass_of_water_standin(1920, 1080, 4, 12),
     "coffee_crop": lambda s: s.coffee_machine_standin(1920, 1080, 4, 10),
+    # configuration 1 of the baseline (the reference's CPU-runnable case): 256 x 256, 16 spp, depth 4
+    "c1_glass256": lambda s: s.glass_of_water_standin(256, 256, 16, 4),
 }
 
 
