@@ -90,9 +90,16 @@ def build_scene(name):
         return getattr(scenes, builder)(**kwargs)
     capi = importlib.import_module(PKG + ".capi")
     tmp = tempfile.mkdtemp(prefix="bdpt_scene_")
+    # the loader reports "Triangles: N" on stdout like the reference's (scene_loader.h:521); this program's stdout
+    # carries one JSON line and nothing else, so the report goes to stderr
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
     try:
         flat = capi.load_scene_file(scenes.write_standin_assets(os.path.join(SCENE_FILES, yaml_name), tmp))
     finally:
+        os.dup2(saved, 1)
+        os.close(saved)
         shutil.rmtree(tmp, ignore_errors=True)
     c = flat.camera
     c.image_width = kwargs["image_width"]

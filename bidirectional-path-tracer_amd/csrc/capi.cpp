@@ -262,8 +262,8 @@ bool pipeline_can_walk(const bdpt_scene* scene) { return (int)scene->host.sah_st
 // fixed_ws != null: the per-sample state lives in that caller-provided region of fixed_bytes bytes and nothing is
 // allocated; otherwise in the context's own allocation, grown on demand up to the context's workspace limit.
 int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, uint64_t seed, const int32_t* rows,
-                     int x0, int x1, int64_t n_owned, double* d_fb, int stats_mode, bool time_stages, hipStream_t stream,
-                     void* fixed_ws, size_t fixed_bytes) {
+                     int x0, int x1, int64_t n_owned, double* d_fb, int stats_mode, bool time_stages, bool unidirectional,
+                     hipStream_t stream, void* fixed_ws, size_t fixed_bytes) {
     const Knobs& kn = ctx->knobs;
     const int depth = cam->max_depth;
     const int64_t spp = (int64_t)cam->sqrt_spp * cam->sqrt_spp;
@@ -272,8 +272,9 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     // connection stage are left out altogether (what k_gen_light decides per sample, decided once per scene), and
     // no path vertex, visibility bit or shadow ray needs room.  The counting modes still run everything: they
     // report the draws and pairs of every sample.
-    const bool connections = scene->host.has_lambertian || stats_mode != 0;
-    const size_t vslots = connections ? 2 * (size_t)(depth > 0 ? depth : 1) : 0;
+    // (the unidirectional estimator forms no connections; it keeps one record per level of its recursion instead)
+    const bool connections = !unidirectional && (scene->host.has_lambertian || stats_mode != 0);
+    const size_t vslots = unidirectional ? (size_t)(depth > 0 ? depth : 1) : (connections ? 2 * (size_t)(depth > 0 ? depth : 1) : 0);
     const uint32_t vis_words = connections ? (uint32_t)((depth > 0 ? depth : 1) + 63) / 64 : 0;
     const size_t shadow_per_slot = connections ? (size_t)(depth > 0 ? depth : 1) : 0;
     if (!pipeline_can_walk(scene)) return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
@@ -446,9 +447,18 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
 
         HIP_TRY(hipMemsetAsync(C, 0, n_counters * 4, st));
         HIP_TRY(wf_gen_eye(scene->dev, gcam, wb, b, cfg, st));
-        // eye subpath: camera.h:303 -> trace_path(r, depth, ...)
         int cur = 0;
-        for (int k = 0; k < depth; k++) {
+        // unidirectional estimator: camera.h:255-292, one launch pair per level of the recursion
+        for (int k = 0; k < depth && unidirectional; k++) {
+            const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
+            const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
+            { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
+            const int nxt = (k == 0) ? 0 : (cur ^ 1);
+            HIP_TRY(wf_shade_unidirectional(scene->dev, gcam, wb, b, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k, k == depth - 1, cfg, stats, st));
+            cur = nxt;
+        }
+        // eye subpath: camera.h:303 -> trace_path(r, depth, ...)
+        for (int k = 0; k < depth && !unidirectional; k++) {
             const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
             const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
             { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
@@ -506,14 +516,14 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     const bool want_stats = stats_mode != 0;
     const bool want_time = (p->flags & BDPT_RENDER_TIME_KERNEL) != 0;
     const bool time_stages = (p->flags & BDPT_RENDER_TIME_STAGES) != 0;
-    const bool unidirectional = (p->flags & BDPT_RENDER_UNIDIRECTIONAL) != 0;     // single-kernel path only
+    const bool unidirectional = (p->flags & BDPT_RENDER_UNIDIRECTIONAL) != 0;
     // Reference-equivalent counters need the reference's traversal of every shadow ray: that is the single-kernel
     // path, which also takes over when the four-wide hierarchy is deeper than the pipeline's traversal stack.
     // Everything else runs the wavefront pipeline unless the caller asks otherwise.
-    const bool single_kernel = stats_mode == 1 || unidirectional || (p->flags & BDPT_RENDER_MEGAKERNEL) || !pipeline_can_walk(scene);
+    const bool single_kernel = stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || !pipeline_can_walk(scene);
     if (fixed_ws && (single_kernel || time_stages))
         return fail(BDPT_ERR_UNSUPPORTED, pipeline_can_walk(scene)
-                        ? "bdpt_render_device_static supports the flags BDPT_RENDER_COUNT_WORK and BDPT_RENDER_TIME_KERNEL only"
+                        ? "bdpt_render_device_static supports the flags BDPT_RENDER_COUNT_WORK, BDPT_RENDER_TIME_KERNEL and BDPT_RENDER_UNIDIRECTIONAL only"
                         : "BVH deeper than the traversal stack (the single-kernel path that would render it allocates)");
     ctx->stats_valid = false;
     ctx->stage_valid = false;
@@ -544,7 +554,7 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
         if (single_kernel)
             rc = render_megakernel(ctx, scene, cam, p->seed, rows, (int32_t)n_rows, x0, x1, n_owned, d_fb, stats_mode, unidirectional, stream);
         else
-            rc = render_wavefront(ctx, scene, cam, p->seed, rows, x0, x1, n_owned, d_fb, stats_mode, time_stages, stream, fixed_ws, fixed_bytes);
+            rc = render_wavefront(ctx, scene, cam, p->seed, rows, x0, x1, n_owned, d_fb, stats_mode, time_stages, unidirectional, stream, fixed_ws, fixed_bytes);
         if (rc != BDPT_OK) return rc;
         ctx->stage_valid = time_stages && !single_kernel;
     }

@@ -626,6 +626,74 @@ BDPT_DEV double light_tri_pdf(const SceneDev& sc, uint32_t tri_id, V3 origin, V3
 // (or `attenuation * sample` for metal and dielectric); here the walk goes forward storing one record per
 // bounce (factor and pdf) in the vertex workspace, and the same expressions are folded from the last
 // bounce to the first.
+//
+// One level of that recursion after its hit was found: either the value the level returns without going deeper
+// (an emitter; a lambertian surface whose mixture pdf came out as zero), or the record of the level (p = factor,
+// n.x = pdf, 0 marking `attenuation * sample`) and the ray of the next level.
+struct UniBounce {
+    bool cont;
+    V3 value;         // when !cont
+    Vertex rec;       // when cont
+    V3 o, d;
+};
+template <int STATS>
+BDPT_DEV void unidirectional_bounce(const SceneDev& sc, V3 o, V3 d, const HitLite& h, Rng& rng, Counters& c, UniBounce& out) {
+    const GpuTriAux ax = sc.aux[h.tri];
+    const GpuMaterial m = sc.mats[sc.tris[h.tri].material];
+    V3 p = add(o, scl(h.t, d));
+    V3 outward = ld3(ax.normal);
+    bool front_face = dot(d, outward) < 0;
+    V3 normal = front_face ? outward : neg(outward);
+    out.cont = false;
+    out.value = mk(0, 0, 0);
+    if (m.type == 3) { out.value = front_face ? ld3(m.rgb) : mk(0, 0, 0); return; }      // emitted, no scatter
+    out.rec.n = mk(0, 0, 0); out.rec.T = mk(0, 0, 0); out.rec.info = 0;
+    if (m.type == 1 || m.type == 2) {
+        Bounce bo;
+        shade_bounce<true>(sc, o, d, h, mk(1.0, 1.0, 1.0), rng, bo);      // bo.T = 1 * attenuation = attenuation
+        out.rec.p = bo.T;
+        out.o = bo.o; out.d = bo.d;
+        out.cont = true;
+        return;
+    }
+    // lambertian: direction from the mixture, pdf.h:73-87
+    V3 w;
+    (void)onb_transform(normal, mk(0, 0, 0), w);
+    V3 direction;
+    if (rng.next() < 0.5) {
+        // triangle_collection::random: random_int(0, size - 1) = int(0 + (size - 0) * random_double()), main.h:34-42
+        int idx = (int)(0.0 + ((double)(int)sc.n_lights - 0.0) * rng.next());
+        if (idx > (int)sc.n_lights - 1) idx = (int)sc.n_lights - 1;       // (out of range in the reference)
+        const GpuTri lt = sc.tris[sc.light_tris[idx]];
+        double u = rng.next();
+        double v = rng.next();
+        if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
+        V3 lp = add(add(ld3(lt.v0), scl(u, ld3(lt.e1))), scl(v, ld3(lt.e2)));
+        direction = sub(lp, p);
+    } else {
+        V3 w2;
+        direction = onb_transform(normal, random_cosine_direction(rng), w2);
+    }
+    // triangle_collection::pdf_value: every light triangle, in order
+    double weight = 1.0 / (double)sc.n_lights;
+    double sum = 0.0;
+    for (uint32_t k = 0; k < sc.n_lights; k++) sum += weight * light_tri_pdf<STATS>(sc, sc.light_tris[k], p, direction, c);
+    double cosine_theta = dot(unit(direction), w);
+    double pdf_value = 0.5 * sum + 0.5 * __builtin_fmax(0.0, cosine_theta / kPi);
+    if (pdf_value <= 0) return;               // returns the (zero) emission of a lambertian surface
+    double cos_theta = dot(normal, unit(direction));
+    double scattering_pdf = cos_theta < 0 ? 0 : cos_theta / kPi;
+    out.rec.p = scl(scattering_pdf, ld3(m.rgb));
+    out.rec.n.x = pdf_value;
+    out.o = p; out.d = direction;
+    out.cont = true;
+}
+// the value a level returns given its record and the value of the level below
+BDPT_DEV V3 unidirectional_fold(const Vertex& rec, V3 below) {
+    if (rec.n.x == 0.0) return mulv(rec.p, below);
+    return add(mk(0, 0, 0), divs(mulv(rec.p, below), rec.n.x));
+}
+
 template <int STATS, class Mem>
 BDPT_DEV V3 sample_radiance_unidirectional(const Mem& mem, const SceneDev& sc, const GpuCamera& cam, int i, int j, int s_i,
                                            int s_j, uint64_t seed, const VertexStore& store, Counters& c, uint32_t& draws) {
@@ -641,60 +709,13 @@ BDPT_DEV V3 sample_radiance_unidirectional(const Mem& mem, const SceneDev& sc, c
         if (remaining <= 0) break;              // camera.h:258-259
         HitLite h;
         if (!walk<STATS, false>(mem, o, d, 0.001, kInf, h, c)) { result = ld3(cam.background); break; }
-        const GpuTriAux ax = sc.aux[h.tri];
-        const GpuMaterial m = sc.mats[sc.tris[h.tri].material];
-        V3 p = add(o, scl(h.t, d));
-        V3 outward = ld3(ax.normal);
-        bool front_face = dot(d, outward) < 0;
-        V3 normal = front_face ? outward : neg(outward);
-        if (m.type == 3) { result = front_face ? ld3(m.rgb) : mk(0, 0, 0); break; }      // emitted, no scatter
-        Vertex rec;                              // p = factor, n.x = pdf (0 marks `attenuation * sample`)
-        rec.n = mk(0, 0, 0); rec.T = mk(0, 0, 0); rec.info = 0;
-        if (m.type == 1 || m.type == 2) {
-            Bounce bo;
-            shade_bounce<true>(sc, o, d, h, mk(1.0, 1.0, 1.0), rng, bo);      // bo.T = 1 * attenuation = attenuation
-            rec.p = bo.T;
-            store.put(n++, rec);
-            o = bo.o; d = bo.d;
-            continue;
-        }
-        // lambertian: direction from the mixture, pdf.h:73-87
-        V3 w;
-        (void)onb_transform(normal, mk(0, 0, 0), w);
-        V3 direction;
-        if (rng.next() < 0.5) {
-            // triangle_collection::random: random_int(0, size - 1) = int(0 + (size - 0) * random_double()), main.h:34-42
-            int idx = (int)(0.0 + ((double)(int)sc.n_lights - 0.0) * rng.next());
-            if (idx > (int)sc.n_lights - 1) idx = (int)sc.n_lights - 1;       // (out of range in the reference)
-            const GpuTri lt = sc.tris[sc.light_tris[idx]];
-            double u = rng.next();
-            double v = rng.next();
-            if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
-            V3 lp = add(add(ld3(lt.v0), scl(u, ld3(lt.e1))), scl(v, ld3(lt.e2)));
-            direction = sub(lp, p);
-        } else {
-            V3 w2;
-            direction = onb_transform(normal, random_cosine_direction(rng), w2);
-        }
-        // triangle_collection::pdf_value: every light triangle, in order
-        double weight = 1.0 / (double)sc.n_lights;
-        double sum = 0.0;
-        for (uint32_t k = 0; k < sc.n_lights; k++) sum += weight * light_tri_pdf<STATS>(sc, sc.light_tris[k], p, direction, c);
-        double cosine_theta = dot(unit(direction), w);
-        double pdf_value = 0.5 * sum + 0.5 * __builtin_fmax(0.0, cosine_theta / kPi);
-        if (pdf_value <= 0) break;               // returns the (zero) emission of a lambertian surface
-        double cos_theta = dot(normal, unit(direction));
-        double scattering_pdf = cos_theta < 0 ? 0 : cos_theta / kPi;
-        rec.p = scl(scattering_pdf, ld3(m.rgb));
-        rec.n.x = pdf_value;
-        store.put(n++, rec);
-        o = p; d = direction;
+        UniBounce ub;
+        unidirectional_bounce<STATS>(sc, o, d, h, rng, c, ub);
+        if (!ub.cont) { result = ub.value; break; }
+        store.put(n++, ub.rec);
+        o = ub.o; d = ub.d;
     }
-    for (int k = n - 1; k >= 0; k--) {
-        const Vertex rec = store.get(k);
-        if (rec.n.x == 0.0) result = mulv(rec.p, result);
-        else result = add(mk(0, 0, 0), divs(mulv(rec.p, result), rec.n.x));
-    }
+    for (int k = n - 1; k >= 0; k--) result = unidirectional_fold(store.get(k), result);
     draws = rng.counter;
     return result;
 }

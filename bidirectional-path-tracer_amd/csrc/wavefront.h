@@ -76,6 +76,10 @@ hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& w
                     const uint32_t* queue_in, const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
                     uint32_t* count_out, bool last_bounce, bool store_vertices, const WfLaunchCfg& cfg, unsigned long long* stats,
                     hipStream_t st);
+// one level of camera::path_trace_color (the unidirectional estimator): records into wb.vtx slot `level`
+hipError_t wf_shade_unidirectional(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const uint32_t* queue_in,
+                                   const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out, uint32_t* count_out, int level,
+                                   bool last_level, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
 hipError_t wf_gen_light(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* queue_out,
                         uint32_t* count_out, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
 hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* conn_count,

@@ -717,6 +717,72 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
     if (STATS) flush_wave_counter(&stats[10], n_stored);
 }
 
+// ------------------------------------------------------------------ one level of the unidirectional estimator
+// camera::path_trace_color (camera.h:255-292) as a pipeline stage: the level's record goes to the sample's vertex
+// workspace (slot `level`), a sample whose recursion ends here folds its records back to front into its radiance.
+template <bool STATS>
+__global__ __launch_bounds__(kStageBlock) void k_shade_unidirectional(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
+                                                                      const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
+                                                                      uint32_t* count_out, int level, int last_level, unsigned long long* stats) {
+    __shared__ uint32_t s_wave[kStageWaves];
+    __shared__ uint32_t s_base;
+    const uint32_t count = count_in_ptr ? *count_in_ptr : count_in_imm;
+    const uint64_t ns = wb.ns;
+    unsigned long long draws = 0, samples = 0;
+    for (uint32_t tile = blockIdx.x * kStageTile; tile < count; tile += gridDim.x * kStageTile) {
+        bool cont[kStagePerThread];
+        uint32_t slots[kStagePerThread];
+#pragma unroll 1
+        for (int j = 0; j < kStagePerThread; j++) {
+            const uint32_t k = tile + (uint32_t)j * kStageBlock + threadIdx.x;
+            slots[j] = 0;
+            cont[j] = false;
+            if (k >= count) continue;
+            const uint32_t slot = queue_in ? queue_in[k] : k;
+            slots[j] = slot;
+            int pi, pj, ps;
+            if (!slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
+            const V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
+            const V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
+            const int32_t pos = wb.hit_tri[slot];
+            HitLite h;
+            h.tri = pos < 0 ? -1 : sc.stris[pos].pad; h.t = 0; h.u = 0; h.v = 0;
+            if (pos == kHitRedo) h.tri = redo_closest(sc, o, d, kInf, h.t);
+            else if (pos >= 0) h.t = wb.hit[slot];
+            V3 value = mk(0, 0, 0);           // what the innermost level returns
+            int n_records = level;
+            Rng rng = slot_rng(cam, b, slot, wb.ctr[slot]);
+            if (h.tri < 0) {
+                value = ld3(cam.background);                                    // camera.h:264-265
+            } else {
+                Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                UniBounce ub;
+                unidirectional_bounce<kStatsOff>(sc, o, d, h, rng, c, ub);
+                if (!ub.cont) {
+                    value = ub.value;
+                } else {
+                    slot_store(wb, slot).put(level, ub.rec);
+                    n_records = level + 1;
+                    if (!last_level) {
+                        cont[j] = true;
+                        wb.ray[slot] = ub.o.x; wb.ray[ns + slot] = ub.o.y; wb.ray[2 * ns + slot] = ub.o.z;
+                        wb.ray[3 * ns + slot] = ub.d.x; wb.ray[4 * ns + slot] = ub.d.y; wb.ray[5 * ns + slot] = ub.d.z;
+                        wb.ctr[slot] = rng.counter;
+                    }
+                    // (at the last level the next call has no depth left and returns zero, camera.h:258-259)
+                }
+            }
+            if (!cont[j]) {
+                for (int q = n_records - 1; q >= 0; q--) value = unidirectional_fold(slot_store(wb, slot).get(q), value);
+                wb.result[slot] = value.x; wb.result[ns + slot] = value.y; wb.result[2 * ns + slot] = value.z;
+                if (STATS) { draws += rng.counter; samples++; }
+            }
+        }
+        tile_append(cont, slots, queue_out, count_out, s_wave, &s_base);
+    }
+    if (STATS) { flush_wave_counter(&stats[8], draws); flush_wave_counter(&stats[9], samples); }
+}
+
 // ------------------------------------------------------------------ light subpath start
 template <bool STATS>
 __global__ __launch_bounds__(kStageBlock) void k_gen_light(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, uint32_t* queue_out,
@@ -1166,6 +1232,15 @@ hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& w
         if (stats) hipLaunchKernelGGL((k_shade<false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
         else hipLaunchKernelGGL((k_shade<false, false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
     }
+    return hipGetLastError();
+}
+
+hipError_t wf_shade_unidirectional(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const uint32_t* queue_in,
+                                   const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out, uint32_t* count_out, int level,
+                                   bool last_level, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
+    dim3 grid(cfg.stream_blocks), block(kStageBlock);
+    if (stats) hipLaunchKernelGGL((k_shade_unidirectional<true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, level, last_level ? 1 : 0, stats);
+    else hipLaunchKernelGGL((k_shade_unidirectional<false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, level, last_level ? 1 : 0, stats);
     return hipGetLastError();
 }
 

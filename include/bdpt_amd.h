@@ -109,7 +109,9 @@ typedef struct bdpt_render_params {
                                        (bdpt_render_get_kernel_ms) */
 #define BDPT_RENDER_UNIDIRECTIONAL 32 /* estimate with camera::path_trace_color (src/camera.h:255-292: mixture of light and
                                        BSDF sampling) instead of bidirectional_color - what the reference's ray_color
-                                       does when `lights` is not a triangle_collection (camera.h:245-253) */
+                                       does when `lights` is not a triangle_collection (camera.h:245-253).  Runs on the
+                                       wavefront pipeline like the default estimator (on the single kernel with
+                                       BDPT_RENDER_MEGAKERNEL / BDPT_RENDER_COUNT_STATS) */
 #define BDPT_RENDER_TIME_STAGES 16  /* additionally record a HIP event pair around every ray-traversal launch, on the
                                        internal stream it is launched on (bdpt_render_get_stage_ms); wavefront pipeline only */
 
@@ -219,8 +221,8 @@ int bdpt_render_device(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_ca
  * object (every GPU the library runs on holds its copy until the process ends), and the pipeline cuts the frame
  * into batches that fit it.  No counterpart in the reference.  Limits: the samples of ONE pixel must fit the
  * workspace - about samples x (152 + 240 x max_depth) bytes, e.g. 1024 samples at depth 12 need 3 MB, fine; 65536
- * samples at depth 40 do not - otherwise BDPT_ERR_UNSUPPORTED; flags other than BDPT_RENDER_COUNT_WORK and
- * BDPT_RENDER_TIME_KERNEL are refused (they need buffers of their own).  All calls on one GPU share that GPU's
+ * samples at depth 40 do not - otherwise BDPT_ERR_UNSUPPORTED; flags other than BDPT_RENDER_COUNT_WORK,
+ * BDPT_RENDER_TIME_KERNEL and BDPT_RENDER_UNIDIRECTIONAL are refused (they need buffers of their own).  All calls on one GPU share that GPU's
  * workspace, whatever the context: calls that overlap on one GPU race, so issue them on one stream or order them
  * with events.  Smaller batches than bdpt_render_device's make it the slower of the two on large frames. */
 int bdpt_render_device_static(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam,

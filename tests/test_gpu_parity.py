@@ -517,9 +517,17 @@ def test_unidirectional_estimator_matches_reference(name, scenes, ctx):
     cam = capi.camera_initialize(flat.camera)
     seed = int(g["render_seed"][0])
     fb = sc.render(cam, seed=seed, unidirectional=True)
-    assert_bit_equal(fb, g["framebuffer"], "unidirectional framebuffer")
+    assert_bit_equal(fb, g["framebuffer"], "unidirectional framebuffer, wavefront pipeline")
+    assert_bit_equal(sc.render(cam, seed=seed, unidirectional=True, megakernel=True), g["framebuffer"], "unidirectional framebuffer, single kernel")
+    fbw, sw = sc.render(cam, seed=seed, unidirectional=True, want_stats="work")
+    assert_bit_equal(fbw, g["framebuffer"], "unidirectional framebuffer, pipeline with work counters")
+    assert sw.samples == cam.image_width * cam.image_height * cam.sqrt_spp ** 2 and sw.shadow_rays == 0 and sw.connection_pairs == 0
     fb2, st = sc.render(cam, seed=seed, unidirectional=True, want_stats=True)
     assert_bit_equal(fb2, g["framebuffer"], "unidirectional framebuffer, counting mode")
     want = [int(v) for v in g["render_stats"]]
     assert [st.rays_traced, st.aabb_tests, st.aabb_hits, st.bvh_node_visits, st.triangle_tests, st.triangle_hits] == want[:6]
     assert st.rng_draws == want[7]
+    # the pipeline draws what the reference draws (its last level included) and traces one ray fewer per sample that
+    # runs out of depth (the reference counts the call that returns at once, camera.h:256-259)
+    assert sw.rng_draws == st.rng_draws and 0 < sw.rays_traced <= st.rays_traced
+    sc.close()
