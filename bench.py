@@ -98,6 +98,8 @@ def build_scene(name):
     try:
         flat = capi.load_scene_file(scenes.write_standin_assets(os.path.join(SCENE_FILES, yaml_name), tmp))
     finally:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)        # the C library's own buffer, while descriptor 1 still points at stderr
         os.dup2(saved, 1)
         os.close(saved)
         shutil.rmtree(tmp, ignore_errors=True)
