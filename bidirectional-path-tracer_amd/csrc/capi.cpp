@@ -63,10 +63,6 @@ struct Knobs {
     int leaf;
     int leaf_inner;       // 0: half the leaf threshold
     int chunk;
-    int fused;            // 1: scenes without connectable surfaces render with the whole-path kernel
-    int fused_blocks_per_cu;
-    int fused_chunk;
-    int fused_shade;
 };
 
 Knobs read_knobs() {
@@ -81,10 +77,6 @@ Knobs read_knobs() {
     k.leaf = env_int("BDPT_WF_LEAF", 32, 1, 64);
     k.leaf_inner = env_int("BDPT_WF_LEAF_INNER", 0, 0, 64);
     k.chunk = env_int("BDPT_WF_CHUNK", 512, 1, 1 << 20);
-    k.fused = env_int("BDPT_WF_FUSED", 1, 0, 1);
-    k.fused_blocks_per_cu = env_int("BDPT_WF_FUSED_BLOCKS_PER_CU", 0, 0, 16);
-    k.fused_chunk = env_int("BDPT_WF_FUSED_CHUNK", 64, 1, 1 << 20);
-    k.fused_shade = env_int("BDPT_WF_FUSED_SHADE", 16, 1, 64);
     return k;
 }
 
@@ -256,13 +248,6 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     cfg.leaf_inner = kn.leaf_inner > 0 ? kn.leaf_inner : (cfg.leaf_threshold > 1 ? cfg.leaf_threshold / 2 : 1);
     cfg.chunk = (uint32_t)kn.chunk;   // measured: the cursor is one address, and its atomics cost more than a coarser split
     cfg.stream_blocks = ctx->cu_count * 8;
-    {
-        int fused_per_cu = wf_delta_paths_blocks_per_cu(cfg);
-        if (kn.fused_blocks_per_cu > 0) fused_per_cu = kn.fused_blocks_per_cu;
-        cfg.delta_blocks = ctx->cu_count * fused_per_cu;
-    }
-    cfg.delta_chunk = (uint32_t)kn.fused_chunk;
-    cfg.shade_threshold = kn.fused_shade;
     return BDPT_OK;
 }
 
@@ -412,7 +397,6 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
 
     const GpuCamera gcam = to_gpu_camera(*cam);
     unsigned long long* stats = stats_mode ? ctx->stats : nullptr;
-    const bool whole_paths = kn.fused && !connections && !unidirectional && depth > 0;
 
     ctx->stage_pairs = 0;
     ctx->stage_kind.clear();
@@ -462,12 +446,6 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         const uint32_t n_slots = (uint32_t)((int64_t)b.n_pixels * spp);
 
         HIP_TRY(hipMemsetAsync(C, 0, n_counters * 4, st));
-        if (whole_paths) {
-            // no connectable surface in the scene: the eye subpaths of the batch, start to end, in one kernel
-            { int rc = timed(0, st, [&] { return wf_delta_paths(scene->dev, gcam, wb, b, n_slots, eye_cursor(0), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
-            HIP_TRY(wf_resolve(gcam, wb, b, d_fb, cfg, st));
-            continue;
-        }
         HIP_TRY(wf_gen_eye(scene->dev, gcam, wb, b, cfg, st));
         int cur = 0;
         // unidirectional estimator: camera.h:255-292, one launch pair per level of the recursion

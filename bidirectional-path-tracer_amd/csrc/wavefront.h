@@ -65,10 +65,6 @@ struct WfLaunchCfg {
     uint32_t chunk;           // ray indices a wave takes from the global cursor at a time
     uint32_t top_nodes;       // 128-byte records of the top tree levels each such workgroup keeps in LDS
     int lds_stack;            // traversal stack entries per lane kept in LDS (the rest of the stack is scratch)
-    // whole-path kernel of scenes without connectable surfaces (wf_delta_paths)
-    int delta_blocks;         // its persistent grid
-    uint32_t delta_chunk;     // samples a wave takes from the cursor at a time
-    int shade_threshold;      // lanes of a wave that must have their hit before the wave turns to the bounces
 };
 
 // counts of the work done, accumulated by the kernels when `stats` is non-null (bdpt_stats order)
@@ -97,12 +93,6 @@ hipError_t wf_conn_accum(const SceneDev& sc, const GpuCamera& cam, const WfBuffe
                          const WfLaunchCfg& cfg, hipStream_t st);
 hipError_t wf_resolve(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, double* fb, const WfLaunchCfg& cfg,
                       hipStream_t st);
-
-// Scenes without a lambertian triangle (no path vertex is stored, no connection formed): the samples 0 .. count-1 of
-// the batch from the camera ray to the end of the eye subpath in ONE persistent kernel; only wb.result is written.
-hipError_t wf_delta_paths(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t count, uint32_t* cursor,
-                          const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
-int wf_delta_paths_blocks_per_cu(const WfLaunchCfg& cfg);
 
 // sets the LDS limit of the traversal kernels for this launch shape and reports how many workgroups fit a CU
 hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu);

@@ -634,253 +634,6 @@ __device__ __attribute__((noinline)) int32_t redo_closest(const SceneDev& sc, V3
     return h.tri;
 }
 
-// ------------------------------------------------------------------ whole eye subpaths in one kernel
-// A scene without a lambertian triangle stores no path vertex and forms no connection (see k_shade): a sample is
-// its eye subpath alone, a chain of specular bounces that ends on an emitter, in the background or at the depth
-// limit.  For such a scene the whole chain runs inside the persistent traversal loop: a lane keeps its sample's
-// ray, throughput and stream position in registers from the camera ray to the end, and nothing but the sample's
-// radiance is ever written - no per-bounce launches, queues or ray state in memory.  The loop gets a third kind
-// of iteration beside "interior record" and "triangle": lanes whose ray found its closest hit wait until
-// `shade_threshold` of them have one (or no lane is traversing) and are then shaded together - the bounce is the
-// code of k_shade, the arithmetic of one sample is untouched.
-template <bool STATS, class Mem>
-BDPT_DEV void trace_delta_paths(const Mem& mem, const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b,
-                                uint32_t count, uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk,
-                                const int kLeafThreshold, const int kLeafInner, const int kShadeThreshold, double* lds_stack,
-                                const int kLdsStack, const uint32_t first_base) {
-    const float bound_f32 = float_up(sc.coord_bound);
-    const GrazeBits gbits = graze_bits(sc.bary_margin, wb.ray_len);
-    const int depth = cam.max_depth;
-    const uint64_t ns = wb.ns;
-    bool has = false, waiting = false, redo = false;
-    uint32_t slot = 0;
-    int32_t cur = kPop;
-    uint32_t leaf_next = 0, leaf_left = 0;
-    int sp = 0;
-    double stk_quad[kQuadStackDepth];
-    double* const lstk = lds_stack + threadIdx.x;
-    auto push = [&](double e) {
-        if (sp < kLdsStack) lstk[sp * kBlock] = e;
-        else stk_quad[sp - kLdsStack] = e;
-        sp++;
-    };
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
-    double closest = 0;
-    RayF32 rf = {};
-    int32_t hit_pos = -1;
-    uint32_t ctr = 0;
-    int bounce = 0;
-    uint32_t pool_next = 0, pool_end = 0;     // wave-uniform
-    if (first_base < count) { pool_next = first_base; pool_end = (first_base + kChunk < count) ? first_base + kChunk : count; }
-    bool exhausted = (pool_next == pool_end);
-    uint32_t n_records = 0, n_box_hits = 0, n_tri = 0, n_tri_hits = 0, n_rays = 0;
-    unsigned long long n_draws = 0, n_samples = 0;
-
-    auto start_ray = [&]() {
-        rf = ray_f32(o, d, bound_f32);
-        closest = kInf;
-        cur = 0;
-        leaf_left = 0;
-        sp = 0;
-        hit_pos = -1;
-        redo = false;
-        has = true;
-        if (STATS) n_rays++;
-    };
-
-    for (;;) {
-        // ---- new samples for idle lanes
-        const unsigned long long idle = __ballot(!has && !waiting);
-        const int n_idle = __builtin_popcountll(idle);
-        if (!exhausted && (n_idle >= kRefillThreshold)) {
-            if (pool_next == pool_end) {
-                uint32_t base = count;
-                if (cursor) {
-                    if (lane_id() == 0) base = atomicAdd(cursor, kChunk);
-                    base = __shfl(base, 0, 64);
-                }
-                if (base >= count) { exhausted = true; pool_next = pool_end = 0; }
-                else { pool_next = base; pool_end = (base + kChunk < count) ? base + kChunk : count; }
-            }
-            const uint32_t avail = pool_end - pool_next;
-            const uint32_t give = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
-            if (!has && !waiting) {
-                const uint32_t r = rank_in_mask(idle);
-                if (r < give) {
-                    slot = pool_next + r;
-                    int pi, pj, ps;
-                    if (slot_to_sample(cam, b, slot, pi, pj, ps)) {
-                        Rng rng;
-                        rng.key = stream_key(b.seed, (uint64_t)pj * (uint64_t)cam.width + (uint64_t)pi, (uint64_t)ps);
-                        rng.counter = 0;
-                        const int s_j = ps / cam.sqrt_spp, s_i = ps - s_j * cam.sqrt_spp;
-                        camera_ray(cam, pi, pj, s_i, s_j, rng, o, d);
-                        T = mk(1.0, 1.0, 1.0);
-                        ctr = rng.counter;
-                        bounce = 0;
-                        if (depth > 0) start_ray();
-                        else { wb.result[slot] = 0.0; wb.result[ns + slot] = 0.0; wb.result[2 * ns + slot] = 0.0; }
-                    } else {
-                        wb.result[slot] = 0.0; wb.result[ns + slot] = 0.0; wb.result[2 * ns + slot] = 0.0;
-                    }
-                }
-            }
-            pool_next += give;
-        }
-        // ---- bounces for the lanes that have their hit
-        const unsigned long long wait_mask = __ballot(waiting);
-        const unsigned long long active = __ballot(has);
-        if (wait_mask != 0 && (__builtin_popcountll(wait_mask) >= kShadeThreshold || active == 0)) {
-            if (waiting) {
-                waiting = false;
-                int32_t tri = hit_pos < 0 ? -1 : sc.stris[hit_pos].pad;
-                double t_hit = closest;
-                if (redo) tri = redo_closest(sc, o, d, kInf, t_hit);
-                V3 value = mk(0, 0, 0);
-                bool go_on = false;
-                if (tri < 0) {
-                    value = add(mk(0, 0, 0), mulv(T, ld3(cam.background)));       // camera.h:337-338
-                } else {
-                    HitLite h;
-                    h.tri = tri; h.t = t_hit; h.u = 0; h.v = 0;
-                    int pi, pj, ps;
-                    slot_to_sample(cam, b, slot, pi, pj, ps);
-                    Rng rng;
-                    rng.key = stream_key(b.seed, (uint64_t)pj * (uint64_t)cam.width + (uint64_t)pi, (uint64_t)ps);
-                    rng.counter = ctr;
-                    Bounce bo;
-                    shade_bounce<true, false>(sc, o, d, h, T, rng, bo);
-                    ctr = rng.counter;
-                    if (bo.emitted) value = add(mk(0, 0, 0), bo.emitted_term);   // camera.h:306-309
-                    if (bo.cont && bounce + 1 < depth) {
-                        o = bo.o; d = bo.d; T = bo.T;
-                        bounce++;
-                        go_on = true;
-                    }
-                }
-                if (go_on) {
-                    start_ray();
-                } else {
-                    wb.result[slot] = value.x; wb.result[ns + slot] = value.y; wb.result[2 * ns + slot] = value.z;
-                    if (STATS) { n_draws += ctr; n_samples++; }
-                }
-            }
-            continue;
-        }
-        if (active == 0) {
-            if (exhausted && wait_mask == 0) break;
-            continue;
-        }
-        // ---- one interior record or one triangle for the traversing lanes (as in traverse_queue)
-        const unsigned long long at_leaf = __ballot(has && leaf_left > 0);
-        const bool leaf_phase = (at_leaf == active) || (__builtin_popcountll(at_leaf) >= kLeafThreshold);
-        bool pop = false, done = false;
-        if (!leaf_phase) {
-            if (has && leaf_left == 0) {
-                const auto nd = mem.wnode(cur);
-                if (STATS) n_records++;
-                double e[4];
-                int n_in = 0;
-                const float closest_up = float_up(closest);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    float near, far;
-                    slab_f32(nd.box[k], rf, closest_up, near, far);
-                    const bool in = (nd.child[k] != kQuadEmpty) && !(far < near);
-                    e[k] = quad_entry(in, near, nd.child[k]);
-                    n_in += in ? 1 : 0;
-                }
-                if (STATS) n_box_hits += (uint32_t)n_in;
-                sort2(e[0], e[1]); sort2(e[2], e[3]); sort2(e[0], e[2]); sort2(e[1], e[3]); sort2(e[1], e[2]);
-                if (sp + 3 <= kLdsStack) {
-                    lstk[(n_in > 3 ? sp : kLdsStack) * kBlock] = e[3];
-                    lstk[(n_in > 2 ? sp + n_in - 3 : kLdsStack) * kBlock] = e[2];
-                    lstk[(n_in > 1 ? sp + n_in - 2 : kLdsStack) * kBlock] = e[1];
-                    sp += n_in > 1 ? n_in - 1 : 0;
-                } else {
-                    if (n_in > 3) push(e[3]);
-                    if (n_in > 2) push(e[2]);
-                    if (n_in > 1) push(e[1]);
-                }
-                if (n_in > 0) cur = quad_entry_child(e[0]);
-                else pop = true;
-            }
-        } else {
-            for (;;) {
-                if (has && leaf_left > 0) {
-                    const GpuTri tr = mem.stri(leaf_next);
-                    leaf_next++;
-                    leaf_left--;
-                    double t, u, v, det;
-                    const bool cand = tri_candidate(tr, o, d, 0.001, t, u, v, det);
-                    const bool inside = cand && t <= closest;
-                    if (STATS) { n_tri++; if (inside) n_tri_hits++; }
-                    const unsigned tied = (unsigned)cand & ((unsigned)nearly_equal(t, closest) | ((unsigned)inside & (unsigned)grazes(tr, u, v, t, det, gbits)));
-                    redo = ((unsigned)redo | tied) != 0u;
-                    const bool better = ((unsigned)inside & ((unsigned)(t < closest) | (unsigned)(hit_pos < 0) | (unsigned)(tr.pad > hit_pos))) != 0u;
-                    closest = better ? t : closest;
-                    hit_pos = better ? tr.pad : hit_pos;
-                    if (leaf_left == 0) pop = true;
-                }
-                if (__builtin_popcountll(__ballot(has && leaf_left > 0)) < kLeafInner) break;
-            }
-        }
-        if (pop) {
-            done = true;
-            while (sp > 0) {
-                sp--;
-                const double e = (sp < kLdsStack) ? lstk[sp * kBlock] : stk_quad[sp - kLdsStack];
-                if (!(closest < (double)quad_entry_near(e))) { cur = quad_entry_child(e); done = false; break; }
-            }
-        }
-        if (has && !done && leaf_left == 0 && cur < 0) {      // arrived at a leaf: ~cur = (first << 2) | (count - 1)
-            const uint32_t code = (uint32_t)~cur;
-            leaf_next = code >> 2;
-            leaf_left = 1u + (code & 3u);
-        }
-        if (done) { has = false; waiting = true; }
-    }
-    if (STATS) {
-        flush_wave_counter(&stats[0], n_rays);
-        flush_wave_counter(&stats[1], 4ull * n_records);
-        flush_wave_counter(&stats[2], n_box_hits);
-        flush_wave_counter(&stats[3], 2ull * n_records);
-        flush_wave_counter(&stats[4], n_tri);
-        flush_wave_counter(&stats[5], n_tri_hits);
-        flush_wave_counter(&stats[8], n_draws);
-        flush_wave_counter(&stats[9], n_samples);
-    }
-}
-
-template <bool STATS, bool LDS_SCENE>
-__global__ __launch_bounds__(kBlock, 4) void k_delta_paths(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, uint32_t count, uint32_t* cursor,
-                                                       unsigned long long* stats, int refill_threshold, uint32_t chunk, uint32_t top_nodes,
-                                                       int leaf_threshold, int leaf_inner, int shade_threshold, uint32_t scene_lds_bytes,
-                                                       int lds_stack) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    double* const l_stack = reinterpret_cast<double*>(smem + scene_lds_bytes);     // [lds_stack + 1][kBlock]
-    // whole paths are long: small chunks, so that the last samples of a batch are spread over all waves
-    const uint32_t wave_chunk = fair_chunk(count, chunk);
-    __shared__ uint32_t s_first;
-    if (threadIdx.x == 0) s_first = atomicAdd(cursor, (blockDim.x >> 6) * wave_chunk);
-    __syncthreads();
-    if (s_first >= count) return;          // the whole workgroup: nothing left for it
-    const uint32_t first_base = s_first + (threadIdx.x >> 6) * wave_chunk;
-    if (LDS_SCENE) {
-        GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
-        GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
-        stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
-        TreeMem<GpuQuadNode> mem{l_nodes, l_tris};
-        trace_delta_paths<STATS>(mem, sc, cam, wb, b, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, shade_threshold, l_stack, lds_stack, first_base);
-    } else {
-        GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
-        const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
-        stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
-        TopLdsMem<GpuQuadNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
-        trace_delta_paths<STATS>(mem, sc, cam, wb, b, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, shade_threshold, l_stack, lds_stack, first_base);
-    }
-}
-
 // ------------------------------------------------------------------ shading of one bounce
 template <bool EYE, bool STATS, bool LAMBERT>
 __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
@@ -1452,35 +1205,6 @@ static hipError_t launch_traverse(const SceneDev& sc, const WfBuffers& wb, const
         else launch_traverse_as<SHADOW, false, false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
     }
     return hipGetLastError();
-}
-
-template <bool STATS, bool LDS_SCENE>
-static hipError_t launch_delta_paths_as(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t count,
-                                        uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    auto fn = k_delta_paths<STATS, LDS_SCENE>;
-    const size_t shm = traverse_lds_bytes(cfg);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, dim3(cfg.delta_blocks), dim3(kBlock), shm, st, sc, cam, wb, b, count, cursor, stats, cfg.refill_threshold,
-                       cfg.delta_chunk, cfg.top_nodes, cfg.leaf_threshold, cfg.leaf_inner, cfg.shade_threshold, (uint32_t)scene_lds_bytes(cfg),
-                       cfg.lds_stack);
-    return hipGetLastError();
-}
-
-hipError_t wf_delta_paths(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t count, uint32_t* cursor,
-                          const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    if (stats) return cfg.lds_scene ? launch_delta_paths_as<true, true>(sc, cam, wb, b, count, cursor, cfg, stats, st)
-                                    : launch_delta_paths_as<true, false>(sc, cam, wb, b, count, cursor, cfg, stats, st);
-    return cfg.lds_scene ? launch_delta_paths_as<false, true>(sc, cam, wb, b, count, cursor, cfg, stats, st)
-                         : launch_delta_paths_as<false, false>(sc, cam, wb, b, count, cursor, cfg, stats, st);
-}
-
-int wf_delta_paths_blocks_per_cu(const WfLaunchCfg& cfg) {
-    int n = 0;
-    const size_t shm = traverse_lds_bytes(cfg);
-    hipError_t e = cfg.lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_delta_paths<false, true>, kBlock, shm)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_delta_paths<false, false>, kBlock, shm);
-    return (e == hipSuccess && n > 0) ? n : 1;
 }
 
 hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
