@@ -85,7 +85,9 @@ struct SceneDev {
     const GpuTri* tris;
     const uint32_t* node_parent;    // parent of every node of `nodes` (kEndOfTree for the root)
     const GpuTri* stris;            // triangles in leaf order; `pad` holds the original triangle id
-    const uint32_t* sleaf;          // per entry of `stris`: the node of `nodes` that holds the triangle
+    const uint32_t* sleaf;          // per entry of `stris`: the node of `nodes` that holds the triangle; bit 31 = ref_nested
+    const uint32_t* tri_leaf;       // the same per triangle of `tris`
+    const int32_t* tri_graze;       // per triangle of `tris`: its grazing threshold (what `xtris` carries in `material`)
     const GpuQuadNode* xnodes;      // closest-hit hierarchy (surface-area heuristic, four children, FP32 boxes)
     const GpuTri* xtris;            // its triangles in its own leaf order; `pad` = position in `stris`; `material` holds
                                     // the high 32 bits of a double instead: the triangle's grazing threshold (wavefront.hip)
@@ -98,6 +100,7 @@ struct SceneDev {
     double coord_bound;             // largest |coordinate| of any box of the closest-hit hierarchy
     double bary_margin;             // a hit closer than this (in barycentric units) to its triangle's outline is re-checked
     uint32_t n_nodes, n_tris, n_mats, n_lights;
+    uint32_t ref_nested;            // 1: every box of `nodes` contains the boxes of the nodes below it
 };
 
 struct RenderLaunch {

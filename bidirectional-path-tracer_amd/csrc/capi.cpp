@@ -233,6 +233,7 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     cfg.lds_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuQuadNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
     cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
     if (!cfg.lds_scene) cfg.lds_bytes = 0;
+    cfg.ref_tree_bytes = cfg.lds_scene ? (((size_t)scene->dev.n_nodes * (sizeof(GpuNode) + sizeof(uint32_t)) + 15) & ~(size_t)15) : 0;
     cfg.top_nodes = (uint32_t)kn.lds_kb * 1024u / 128u;
     cfg.lds_stack = kn.lds_stack;
     int per_cu = 1;
@@ -277,11 +278,14 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const size_t vslots = unidirectional ? (size_t)(depth > 0 ? depth : 1) : (connections ? 2 * (size_t)(depth > 0 ? depth : 1) : 0);
     const uint32_t vis_words = connections ? (uint32_t)((depth > 0 ? depth : 1) + 63) / 64 : 0;
     const size_t shadow_per_slot = connections ? (size_t)(depth > 0 ? depth : 1) : 0;
+    WfLaunchCfg cfg;
+    { int rc = make_launch_cfg(ctx, scene, cfg); if (rc != BDPT_OK) return rc; }
+    const size_t kept_per_slot = cfg.lds_scene ? shadow_per_slot : 0;      // contributions kept by k_conn_gen<., true>
     if (!pipeline_can_walk(scene)) return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     if (n_owned >= ((int64_t)1 << 31)) return fail(BDPT_ERR_UNSUPPORTED, "more than 2^31 pixels in one call");
     // bytes of state per sample slot
     const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 6 + vslots * 10 * sizeof(double) +
-                            vis_words * sizeof(unsigned long long) + shadow_per_slot * 8 * sizeof(double);
+                            vis_words * sizeof(unsigned long long) + (shadow_per_slot * 8 + kept_per_slot * 3) * sizeof(double);
     const size_t n_counters = 8 + 6 * (size_t)(depth > 0 ? depth : 1);
     // Wavefront state of all batches in flight.  Large batches mean few, long launches (a frame is tens of thousands
     // of them), so a host that wants the last tenth of throughput raises the limit (bdpt_context_set_workspace_limit).
@@ -303,8 +307,8 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         }
     }
     int want_streams = kn.streams;
-    // room for the 256-byte alignment of the 14 arrays of a workspace and for its counters
-    const size_t per_stream_overhead = 16 * 256 + align256(n_counters * 4);
+    // room for the 256-byte alignment of the 15 arrays of a workspace and for its counters
+    const size_t per_stream_overhead = 17 * 256 + align256(n_counters * 4);
     if (budget / want_streams <= per_stream_overhead + per_slot * (size_t)spp) want_streams = 1;
     if (budget <= per_stream_overhead + per_slot * (size_t)spp)
         return fail(BDPT_ERR_UNSUPPORTED, fixed_ws ? "the samples of one pixel exceed the static workspace (samples per pixel x depth too large for bdpt_render_device_static)"
@@ -332,6 +336,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const size_t o_tri = take(ns * 4), o_ctr = take(ns * 4), o_cnt = take(ns * 4);
     const size_t o_q0 = take(ns * 4), o_q1 = take(ns * 4), o_cq = take(ns * 4);
     const size_t o_vtx = take(ns * vslots * 10 * 8), o_vis = take(ns * vis_words * 8), o_sh = take(shadow_cap * 8 * 8);
+    const size_t o_contrib = take(ns * kept_per_slot * 3 * 8);
     const size_t o_counters = take(n_counters * 4);
     // Measured: the batches in flight run 2.5 % faster when their workspaces lie at least ~30 GB apart in the
     // allocation than when they are neighbours (a total that large without the spacing does not help).  A frame big
@@ -386,14 +391,13 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         wb.queue[0] = reinterpret_cast<uint32_t*>(base + o_q0); wb.queue[1] = reinterpret_cast<uint32_t*>(base + o_q1);
         wb.conn_queue = reinterpret_cast<uint32_t*>(base + o_cq);
         wb.vtx = reinterpret_cast<double*>(base + o_vtx); wb.vis = reinterpret_cast<unsigned long long*>(base + o_vis);
+        wb.contrib = reinterpret_cast<double*>(base + o_contrib);
         wb.shadow = reinterpret_cast<double*>(base + o_sh); wb.counters = reinterpret_cast<uint32_t*>(base + o_counters);
         wb.ns = ns; wb.shadow_cap = shadow_cap; wb.vis_words = vis_words;
         wb.ray_len_ptr = nullptr;
         wb.ray_len = ray_len;
     }
 
-    WfLaunchCfg cfg;
-    { int rc = make_launch_cfg(ctx, scene, cfg); if (rc != BDPT_OK) return rc; }
 
     const GpuCamera gcam = to_gpu_camera(*cam);
     unsigned long long* stats = stats_mode ? ctx->stats : nullptr;
@@ -738,7 +742,9 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     size_t off_mats = off_aux + align256(h.aux.size() * sizeof(GpuTriAux));
     size_t off_ltri = off_mats + align256(h.mats.size() * sizeof(GpuMaterial));
     size_t off_lacc = off_ltri + align256(h.light_tris.size() * sizeof(uint32_t));
-    size_t total = off_lacc + align256(h.light_accum.size() * sizeof(double));
+    size_t off_tleaf = off_lacc + align256(h.light_accum.size() * sizeof(double));
+    size_t off_tgraze = off_tleaf + align256(h.tri_leaf.size() * sizeof(uint32_t));
+    size_t total = off_tgraze + align256(h.tri_graze.size() * sizeof(int32_t));
     DeviceGuard guard(ctx->device);
     hipError_t e = hipMalloc(&s->d_blob, total);
     if (e != hipSuccess) { delete s; return hip_fail(e, "hipMalloc(scene)"); }
@@ -756,6 +762,8 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
         {off_mats, h.mats.data(), h.mats.size() * sizeof(GpuMaterial)},
         {off_ltri, h.light_tris.data(), h.light_tris.size() * sizeof(uint32_t)},
         {off_lacc, h.light_accum.data(), h.light_accum.size() * sizeof(double)},
+        {off_tleaf, h.tri_leaf.data(), h.tri_leaf.size() * sizeof(uint32_t)},
+        {off_tgraze, h.tri_graze.data(), h.tri_graze.size() * sizeof(int32_t)},
     };
     for (auto& p : parts) {
         e = hipMemcpy(base + p.off, p.src, p.bytes, hipMemcpyHostToDevice);
@@ -767,6 +775,8 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     d.node_parent = reinterpret_cast<const uint32_t*>(base + off_np);
     d.stris = reinterpret_cast<const GpuTri*>(base + off_st);
     d.sleaf = reinterpret_cast<const uint32_t*>(base + off_sl);
+    d.tri_leaf = reinterpret_cast<const uint32_t*>(base + off_tleaf);
+    d.tri_graze = reinterpret_cast<const int32_t*>(base + off_tgraze);
     d.xnodes = reinterpret_cast<const GpuQuadNode*>(base + off_xn);
     d.xtris = reinterpret_cast<const GpuTri*>(base + off_xt);
     d.n_xnodes = (uint32_t)h.xnodes.size();
@@ -781,6 +791,7 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     d.n_tris = (uint32_t)h.tris.size();
     d.n_mats = (uint32_t)h.mats.size();
     d.n_lights = (uint32_t)h.light_tris.size();
+    d.ref_nested = h.ref_nested ? 1u : 0u;
     *out = s;
     return BDPT_OK;
 }

@@ -272,6 +272,7 @@ constexpr uint32_t kVtxMatMask = (1u << 29) - 1;
 struct Vertex {
     V3 p, n, T;
     uint32_t info;
+    uint32_t tri;        // the triangle the vertex lies on (upper half of the record's last slot)
 };
 
 // SoA in global memory: element (slot, field) of thread g lives at ws[(slot*10 + field)*stride + g],
@@ -285,7 +286,7 @@ struct VertexStore {
         b[0] = v.p.x; b[stride] = v.p.y; b[2 * stride] = v.p.z;
         b[3 * stride] = v.n.x; b[4 * stride] = v.n.y; b[5 * stride] = v.n.z;
         b[6 * stride] = v.T.x; b[7 * stride] = v.T.y; b[8 * stride] = v.T.z;
-        b[9 * stride] = __longlong_as_double((long long)v.info);
+        b[9 * stride] = __longlong_as_double((long long)(((unsigned long long)v.tri << 32) | v.info));
     }
     BDPT_DEV Vertex get(int slot) const {
         const double* b = ws + (uint64_t)slot * kVtxDoubles * stride + g;
@@ -293,7 +294,9 @@ struct VertexStore {
         v.p = mk(b[0], b[stride], b[2 * stride]);
         v.n = mk(b[3 * stride], b[4 * stride], b[5 * stride]);
         v.T = mk(b[6 * stride], b[7 * stride], b[8 * stride]);
-        v.info = (uint32_t)__double_as_longlong(b[9 * stride]);
+        const unsigned long long w = (unsigned long long)__double_as_longlong(b[9 * stride]);
+        v.info = (uint32_t)w;
+        v.tri = (uint32_t)(w >> 32);
         return v;
     }
 };
@@ -336,6 +339,7 @@ BDPT_DEV void shade_bounce(const SceneDev& sc, V3 o, V3 d, const HitLite& h, V3 
     out.keep = (m.type == 0 || m.type == 3);
     out.vx.p = p; out.vx.n = normal; out.vx.T = throughput;
     out.vx.info = (uint32_t)mat_id | (m.type == 3 ? kVtxIsLight : 0u) | (front_face ? kVtxFrontFace : 0u);
+    out.vx.tri = (uint32_t)h.tri;
     out.emitted = false;
     out.emitted_term = mk(0, 0, 0);
     out.cont = false;
@@ -534,6 +538,7 @@ BDPT_DEV void sample_emitter(const SceneDev& sc, int depth, Rng& rng, Emitter& e
     e.ev.p = position; e.ev.n = normal;
     e.ev.T = divs(mk(1.0, 1.0, 1.0), pm);
     e.ev.info = (uint32_t)tr.material | kVtxIsLight | kVtxFrontFace;
+    e.ev.tri = (uint32_t)tri_id;
     V3 w;
     V3 ldir = onb_transform(normal, random_cosine_direction(rng), w);      // camera.h:420-423
     V3 dir_unit = unit(ldir);
@@ -647,7 +652,7 @@ BDPT_DEV void unidirectional_bounce(const SceneDev& sc, V3 o, V3 d, const HitLit
     out.cont = false;
     out.value = mk(0, 0, 0);
     if (m.type == 3) { out.value = front_face ? ld3(m.rgb) : mk(0, 0, 0); return; }      // emitted, no scatter
-    out.rec.n = mk(0, 0, 0); out.rec.T = mk(0, 0, 0); out.rec.info = 0;
+    out.rec.n = mk(0, 0, 0); out.rec.T = mk(0, 0, 0); out.rec.info = 0; out.rec.tri = 0;
     if (m.type == 1 || m.type == 2) {
         Bounce bo;
         shade_bounce<true>(sc, o, d, h, mk(1.0, 1.0, 1.0), rng, bo);      // bo.T = 1 * attenuation = attenuation

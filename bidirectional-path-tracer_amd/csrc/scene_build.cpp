@@ -424,6 +424,18 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
             out.stris.push_back(t);
             out.sleaf.push_back(node_of[id]);
         }
+        out.tri_leaf.swap(node_of);
+        // Every box contains the boxes below it, coordinate by coordinate (a parent's box is the min/max of its
+        // children's, padded outwards at most).  The device relies on it (wavefront.hip: reference_reaches), so it is
+        // checked rather than assumed.
+        out.ref_nested = true;
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            const uint32_t p = out.node_parent[i];
+            if (p == kEndOfTree) continue;
+            for (int k = 0; k < 3; k++)
+                if (!(out.nodes[p].lo[k] <= out.nodes[i].lo[k] && out.nodes[i].hi[k] <= out.nodes[p].hi[k])) out.ref_nested = false;
+        }
+        if (out.ref_nested) for (uint32_t& leaf : out.sleaf) leaf |= 0x80000000u;      // where the traversal kernels read it
     }
 
     // closest-hit hierarchy over the same triangles (referenced by their position in `stris`)
@@ -481,6 +493,7 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
         // box is thin on two axes has no such axis pair and is always re-checked (threshold +infinity).
         out.bary_margin = std::fmax(1e-6, 64.0 * 0x1p-52 * 4.0 * out.coord_bound / 1e-4);
         out.xtris.resize(sb.leaf_order.size());
+        out.tri_graze.assign(n_tri, 0);
         for (size_t k = 0; k < sb.leaf_order.size(); k++) {
             GpuTri t = out.stris[sb.leaf_order[k]];
             const uint32_t id = (uint32_t)t.pad;
@@ -492,6 +505,7 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
             uint64_t bits;
             std::memcpy(&bits, &graze, sizeof bits);
             t.material = (int32_t)(uint32_t)(bits >> 32) + 1;            // high word, rounded up
+            out.tri_graze[id] = t.material;
             out.xtris[k] = t;
         }
     }

@@ -16,12 +16,15 @@ struct HostScene {
     std::vector<GpuNode> nodes;          // pre-order (root first); links already threaded
     std::vector<GpuTri> tris;
     std::vector<uint32_t> node_parent;   // parent of every bvh_node (kEndOfTree for the root)
-    std::vector<uint32_t> sleaf;         // per entry of `stris`: the bvh_node that holds the triangle
+    std::vector<uint32_t> sleaf;         // per entry of `stris`: the bvh_node that holds the triangle; bit 31 = ref_nested
     std::vector<GpuTri> stris;           // triangles in leaf order (pad = original id)
+    std::vector<uint32_t> tri_leaf;      // per triangle: the bvh_node that holds it
+    std::vector<int32_t> tri_graze;      // per triangle: grazing threshold (high word of a double, see scene_build.cpp)
     std::vector<GpuQuadNode> xnodes;     // closest-hit hierarchy (binned SAH, four children per record)
     std::vector<GpuTri> xtris;           // its triangles in leaf order (pad = position in stris)
     double coord_bound = 0.0;            // largest |coordinate| of its boxes
     double bary_margin = 1e-6;           // see SceneDev::bary_margin
+    bool ref_nested = false;             // every bvh_node box contains the boxes of the nodes below it
     uint32_t sah_stack = 0;              // most entries its traversal stack can hold at once
     bool has_lambertian = false;         // some triangle has a lambertian material (the only connectable kind of vertex)
     std::vector<GpuTriAux> aux;

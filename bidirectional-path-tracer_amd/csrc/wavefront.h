@@ -26,6 +26,7 @@ struct WfBuffers {
     unsigned long long* vis;   // [vis_words][ns]  visibility bits of the pairs (a, b = 0..) of the current eye vertex a
     uint32_t* queue[2];   // [ns]     live-sample queues (ping-pong)
     uint32_t* conn_queue; // [ns]     samples that have both eye and light vertices
+    double* contrib;      // [depth][3][ns]  what pair (a, b) of the current eye vertex a adds if its shadow ray is clear (scenes staged in LDS only)
     double* shadow;       // [8][shadow_cap]  shadow rays: origin, direction, max_t, tag (slot, b)
     uint32_t* counters;   // queue sizes and work-distribution cursors, zeroed once per batch
     const float* ray_len_ptr;  // upper bound of |direction| over the closest-hit rays: *ray_len_ptr, or ray_len when null
@@ -59,6 +60,7 @@ struct WfLaunchCfg {
     int stream_blocks;        // grid of the grid-stride kernels
     bool lds_scene;
     size_t lds_bytes;
+    size_t ref_tree_bytes;    // LDS copy of the reference's tree (nodes + parents) for scenes staged in LDS
     int refill_threshold;     // a wave fetches new rays when at least this many of its lanes are idle
     int leaf_threshold;       // lanes of a wave that must stand at a leaf before the wave turns to triangle tests
     int leaf_inner;           // ... and it stays with the triangles of those leaves while this many lanes have one left

@@ -4,5 +4,5 @@ R=$GRAFT_REPO_ROOT
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/kt_$tag
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_$tag -- python3 $R/bench.py "$@" --no-cpu-baseline > $R/gpurun_out/kt_$tag/bench.json 2> $R/gpurun_out/kt_$tag/err.log
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_$tag -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extras --no-pmc > $R/gpurun_out/kt_$tag/bench.json 2> $R/gpurun_out/kt_$tag/err.log
 cat $R/gpurun_out/kt_$tag/*/*_kernel_stats.csv | cut -c1-200

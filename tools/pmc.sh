@@ -5,7 +5,7 @@ tag=$1; shift
 ctrs=$1; shift
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc_$tag
-timeout -s KILL 300 rocprofv3 --pmc $ctrs --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 $R/bench.py "$@" --no-cpu-baseline --no-roofline > /dev/null 2> $R/gpurun_out/pmc_$tag/err.log
+timeout -s KILL 300 rocprofv3 --pmc $ctrs --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 $R/bench.py "$@" --no-cpu-baseline --no-roofline --no-extras --no-pmc > /dev/null 2> $R/gpurun_out/pmc_$tag/err.log
 python3 - <<PY
 import csv,glob,collections
 f=sorted(glob.glob('$R/gpurun_out/pmc_$tag/*/*_counter_collection.csv'))[-1]

@@ -4,11 +4,11 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_wf
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O && mkdir -p $O
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/kt_bench.json 2> $O/kt.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-pmc > $O/kt_bench.json 2> $O/kt.err
 echo kt done
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $O/pmc_fetch_bench.json 2> $O/pmc_fetch.err
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-extras --no-pmc > $O/pmc_fetch_bench.json 2> $O/pmc_fetch.err
 echo fetch done
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $O/pmc_write_bench.json 2> $O/pmc_write.err
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-extras --no-pmc > $O/pmc_write_bench.json 2> $O/pmc_write.err
 echo write done
 python3 - <<PY
 import csv, glob, collections, json
