@@ -233,6 +233,7 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     cfg.lds_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuQuadNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
     cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
     if (!cfg.lds_scene) cfg.lds_bytes = 0;
+    cfg.own_test = cfg.lds_scene;
     cfg.ref_tree_bytes = cfg.lds_scene ? (((size_t)scene->dev.n_nodes * (sizeof(GpuNode) + sizeof(uint32_t)) + 15) & ~(size_t)15) : 0;
     cfg.top_nodes = (uint32_t)kn.lds_kb * 1024u / 128u;
     cfg.lds_stack = kn.lds_stack;
@@ -280,12 +281,13 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const size_t shadow_per_slot = connections ? (size_t)(depth > 0 ? depth : 1) : 0;
     WfLaunchCfg cfg;
     { int rc = make_launch_cfg(ctx, scene, cfg); if (rc != BDPT_OK) return rc; }
-    const size_t kept_per_slot = cfg.lds_scene ? shadow_per_slot : 0;      // contributions kept by k_conn_gen<., true>
+    const size_t kept_per_slot = cfg.own_test ? shadow_per_slot : 0;      // contributions kept by k_conn_gen<., true>
     if (!pipeline_can_walk(scene)) return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     if (n_owned >= ((int64_t)1 << 31)) return fail(BDPT_ERR_UNSUPPORTED, "more than 2^31 pixels in one call");
     // bytes of state per sample slot
     const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 6 + vslots * 10 * sizeof(double) +
-                            vis_words * sizeof(unsigned long long) + (shadow_per_slot * 8 + kept_per_slot * 3) * sizeof(double);
+                            vis_words * sizeof(unsigned long long) + (shadow_per_slot * 8 + kept_per_slot * 3) * sizeof(double) +
+                            (connections ? 8 : 0);        // (the slack of the shadow queue, see conn_blocks below)
     const size_t n_counters = 8 + 6 * (size_t)(depth > 0 ? depth : 1);
     // Wavefront state of all batches in flight.  Large batches mean few, long launches (a frame is tens of thousands
     // of them), so a host that wants the last tenth of throughput raises the limit (bdpt_context_set_workspace_limit).
@@ -308,7 +310,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     }
     int want_streams = kn.streams;
     // room for the 256-byte alignment of the 15 arrays of a workspace and for its counters
-    const size_t per_stream_overhead = 17 * 256 + align256(n_counters * 4);
+    const size_t per_stream_overhead = 17 * 256 + align256(n_counters * 4) + (size_t)kConnSlackPerBlock * 8 * sizeof(double);
     if (budget / want_streams <= per_stream_overhead + per_slot * (size_t)spp) want_streams = 1;
     if (budget <= per_stream_overhead + per_slot * (size_t)spp)
         return fail(BDPT_ERR_UNSUPPORTED, fixed_ws ? "the samples of one pixel exceed the static workspace (samples per pixel x depth too large for bdpt_render_device_static)"
@@ -325,7 +327,15 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     // large powers of two at which all components of a slot would fall into the same memory channel.
     if (pixels_per_batch > 2 && pixels_per_batch % 2 == 0) pixels_per_batch--;
     const uint64_t ns = (uint64_t)(pixels_per_batch * spp);
-    const uint64_t shadow_cap = ns * shadow_per_slot;
+    // k_conn_gen's waves take the shadow queue in pieces and may each leave one partly unused: one workgroup per 4096
+    // slots (at most four per compute unit) keeps that below an eighth of an entry per slot
+    {
+        uint64_t blocks = ns / 4096;
+        if (blocks < 1) blocks = 1;
+        if (blocks > (uint64_t)ctx->cu_count * 4) blocks = (uint64_t)ctx->cu_count * 4;
+        cfg.conn_blocks = (uint32_t)blocks;
+    }
+    const uint64_t shadow_cap = connections ? ns * shadow_per_slot + (uint64_t)cfg.conn_blocks * kConnSlackPerBlock : 0;
     const int64_t n_batches = (n_owned + pixels_per_batch - 1) / pixels_per_batch;
     const int n_streams = (int)(n_batches < want_streams ? n_batches : want_streams);
 

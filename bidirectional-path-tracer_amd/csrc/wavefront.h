@@ -55,10 +55,15 @@ struct WfBatch {
     int64_t n_owned;
 };
 
+// unused shadow-queue entries one workgroup of k_conn_gen can leave behind (waves x entries a wave takes at a time)
+constexpr uint32_t kConnSlackPerBlock = 4 * 128;
+
 struct WfLaunchCfg {
     int persistent_blocks;    // grid of the persistent traversal kernels
     int stream_blocks;        // grid of the grid-stride kernels
     bool lds_scene;
+    uint32_t conn_blocks; // workgroups of k_conn_gen (each may leave up to kConnSlackPerBlock unused entries in the shadow queue)
+    bool own_test;        // k_conn_gen tests the light vertex's own triangle (from tables in LDS) and keeps the pairs' contributions
     size_t lds_bytes;
     size_t ref_tree_bytes;    // LDS copy of the reference's tree (nodes + parents) for scenes staged in LDS
     int refill_threshold;     // a wave fetches new rays when at least this many of its lanes are idle

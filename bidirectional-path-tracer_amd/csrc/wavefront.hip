@@ -29,6 +29,8 @@ constexpr int kStageBlock = 256;
 constexpr int kStagePerThread = 4;
 constexpr int kStageTile = kStageBlock * kStagePerThread;
 constexpr int kStageWaves = kStageBlock / 64;
+constexpr uint32_t kShadowChunk = 128;
+static_assert(kConnSlackPerBlock == kStageWaves * kShadowChunk, "the host sizes the shadow queue with this");
 BDPT_DEV void tile_append(const bool (&flag)[kStagePerThread], const uint32_t (&value)[kStagePerThread], uint32_t* queue,
                           uint32_t* count, uint32_t* s_wave, uint32_t* s_base) {
     unsigned long long m[kStagePerThread];
@@ -965,25 +967,27 @@ BDPT_DEV PairMats stage_pair_mats(const SceneDev& sc, double* lds) {
     return PairMats{lds};
 }
 
-// shadow rays of eye vertex `a` against every light vertex of the sample.  Queue space is reserved
-// once per tile (one atomic) for every candidate pair; pairs that turn out to contribute nothing
-// without a ray leave an entry with a negative max_t, which the traversal skips.
+// shadow rays of eye vertex `a` against every light vertex of the sample.  Only pairs that need a ray get a queue
+// entry: a wave takes kShadowChunk entries of the queue at a time (one atomic) and fills them round by round; what
+// is left of its last piece at the end gets a negative max_t, which the traversal skips.
 // The far end point of a shadow ray lies ON a surface at t = max_t, and in most unoccluded pairs rounding makes that
 // surface's own triangle accept (t <= max_t): the reference then calls the pair blocked (camera.h:437).  That
 // triangle is tested here, before any ray exists - it is the light vertex's own triangle, known from the vertex -
 // with the traversal kernel's rules (a hit at the end of the interval counts only if the reference's boxes let it
 // through), so most blocked pairs never become a ray.  "Some triangle accepts and is reachable" does not depend on
-// which such triangle is found first.  Done for scenes whose reference tree is staged in LDS; on a large scene the
-// walk to the root is a long chain of dependent global loads, and most of its pairs are blocked by something the
-// traversal finds sooner (measured on a 0.96 M-triangle lattice: 2 324 -> 1 524 Msamples/s with the test), so those
-// scenes run the instantiation without it (OWN_TEST = false).
+// which such triangle is found first.  Done for scenes whose tables are staged in LDS; on a large scene the test is
+// two dependent loads from random places of global memory per pair, and most of its pairs are blocked by something
+// the traversal finds sooner (measured on a 0.96 M-triangle lattice: 2 361 -> 1 446 Msamples/s with the test, on 10.2 M
+// triangles 1 826 -> 944, on the 51 k-triangle coffee machine 2 859 -> 2 791), so those scenes run the instantiation
+// without it (OWN_TEST = false).
 template <bool STATS, bool OWN_TEST>
 __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera cam, WfBuffers wb, int a,
                                                           const uint32_t* conn_count, uint32_t* shadow_count,
                                                           unsigned long long* stats) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_wave_off[kStageWaves];
-    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_prefix[kStageTile + 1];
+    __shared__ uint32_t s_slot[kStageTile];
     __shared__ double s_pair_mats[kPairMats * 6];
     const PairMats pmats = stage_pair_mats(sc, s_pair_mats);
     RefTree ref{sc.nodes, sc.node_parent};
@@ -1010,18 +1014,19 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
     const uint32_t wave = threadIdx.x >> 6;
     const uint64_t cap = wb.shadow_cap;
     uint32_t n_pairs = 0;
+    uint32_t chunk_next = 0, chunk_end = 0;     // this wave's piece of the shadow queue (the same in all lanes)
     for (uint32_t tile = blockIdx.x * kStageTile; tile < count; tile += gridDim.x * kStageTile) {
-        // pass 1: how many candidate pairs each of this thread's entries has
-        uint32_t slots[kStagePerThread], mine[kStagePerThread];
+        // pass 1: how many candidate pairs each entry of the tile has (a thread looks at kStagePerThread neighbours)
+        uint32_t mine[kStagePerThread];
         uint32_t total = 0;
 #pragma unroll
         for (int j = 0; j < kStagePerThread; j++) {
-            const uint32_t k = tile + (uint32_t)j * kStageBlock + threadIdx.x;
-            slots[j] = 0;
+            const uint32_t el = threadIdx.x * kStagePerThread + (uint32_t)j;
+            const uint32_t k = tile + el;
             mine[j] = 0;
             if (k < count) {
                 const uint32_t slot = wb.conn_queue[k];
-                slots[j] = slot;
+                s_slot[el] = slot;
                 const uint32_t cnt = wb.counts[slot];
                 if ((uint32_t)a < (cnt & 0xFFFu)) {
                     const uint32_t n_light = (cnt >> 12) & 0xFFFu;
@@ -1035,7 +1040,7 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
             }
             total += mine[j];
         }
-        // workgroup-wide exclusive scan of `total`
+        // workgroup-wide exclusive scan: s_prefix[el] = pairs of the tile's entries before entry el
         uint32_t incl = total;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -1044,72 +1049,79 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
         }
         if (lane_id() == 63) s_wave_off[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (int w = 0; w < kStageWaves; w++) { const uint32_t t = s_wave_off[w]; s_wave_off[w] = run; run += t; }
-            s_base = run ? atomicAdd(shadow_count, run) : 0u;
-        }
+        uint32_t run = incl - total;
+        for (uint32_t w = 0; w < wave; w++) run += s_wave_off[w];
+#pragma unroll
+        for (int j = 0; j < kStagePerThread; j++) { s_prefix[threadIdx.x * kStagePerThread + (uint32_t)j] = run; run += mine[j]; }
+        if (threadIdx.x == kStageBlock - 1) s_prefix[kStageTile] = run;
         __syncthreads();
-        // pass 2: the rays.  A wave's entries are ordered by (j, light vertex, lane), not by lane: the lanes that
-        // write in one iteration then write neighbouring entries.
-        uint64_t wave_next = (uint64_t)s_base + s_wave_off[wave];
-#pragma unroll 1
-        for (int j = 0; j < kStagePerThread; j++) {
-            const uint32_t slot = slots[j];
-            Vertex cv, lv_next;
-            V3 f_cam = mk(0, 0, 0);
-            bool cam_ok = false;        // camera.h:458-460: a zero BSDF at the eye vertex ends every pair of it
-            if (mine[j]) {
-                cv = slot_store(wb, slot).get(a);
-                lv_next = slot_store(wb, slot).get(depth);
-                f_cam = pmats.bsdf(sc, cv.info & kVtxMatMask);
-                cam_ok = !(len2(f_cam) <= 0);
-            }
-            for (uint32_t bi = 0;; bi++) {
-                const unsigned long long writers = __ballot(bi < mine[j]);
-                if (writers == 0) break;
-                if (bi < mine[j]) {
-                    const uint64_t e = wave_next + rank_in_mask(writers);
-                    // the next light vertex is on its way while this one is worked on (three waves per SIMD do not
-                    // hide a load's latency behind the ~400 instructions of a pair by themselves)
-                    const Vertex lv = lv_next;
-                    if (bi + 1 < mine[j]) lv_next = slot_store(wb, slot).get(depth + (int)bi + 1);
-                    PairGeom g;
-                    V3 f_light = mk(0, 0, 0);
-                    bool emit = cam_ok && pair_geometry(cv, lv, g);
-                    if (emit) { f_light = pmats.light_factor(sc, lv.info); emit = len2(f_light) > 0; }      // camera.h:462-469
-                    if (OWN_TEST && emit) {
-                        GpuTri own = own_tris[lv.tri];
-                        own.material = own_graze[lv.tri];
-                        double t, u, v, det;
-                        if (tri_candidate(own, g.origin, g.dir_unit, 0.001, t, u, v, det) && t <= g.max_t) {
-                            const bool check = nearly_equal(t, g.max_t) || grazes(own, u, v, t, det, gbits);
-                            if (!check || reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t)) emit = false;
-                        }
-                    }
-                    if (emit) {
-                        if (OWN_TEST) {
-                            // With the test above most rays that are made come back clear: what the pair then adds
-                            // (camera.h:471-474) is kept, and k_conn_accum only adds it.  Without the test most rays
-                            // come back blocked, and recomputing the few clear pairs there is cheaper than keeping
-                            // all of them here (0.96 M-triangle lattice: 2 217 against 2 331 Msamples/s).
-                            const V3 c = pair_contribution(cv, lv, g, f_cam, f_light);
-                            double* cb = wb.contrib + (uint64_t)bi * 3u * ns + slot;
-                            cb[0] = c.x; cb[ns] = c.y; cb[2 * ns] = c.z;
-                        }
-                        wb.shadow[e] = g.origin.x; wb.shadow[cap + e] = g.origin.y; wb.shadow[2 * cap + e] = g.origin.z;
-                        wb.shadow[3 * cap + e] = g.dir_unit.x; wb.shadow[4 * cap + e] = g.dir_unit.y; wb.shadow[5 * cap + e] = g.dir_unit.z;
-                        wb.shadow[6 * cap + e] = g.max_t;
-                        wb.shadow[7 * cap + e] = __longlong_as_double((long long)(((unsigned long long)slot << 16) | bi));
-                    } else {
-                        wb.shadow[6 * cap + e] = -1.0;
+        const uint32_t n_tile_pairs = s_prefix[kStageTile];
+        // pass 2: the pairs of the tile, one per thread and round whatever entry they belong to - the samples of a
+        // tile have eye and light subpaths of all lengths, and a loop per entry would leave most lanes of a wave idle
+        // (measured in a Cornell box: 12 of 64 lanes at work)
+        for (uint32_t p0 = 0; p0 < n_tile_pairs; p0 += kStageBlock) {
+            const uint32_t p = p0 + threadIdx.x;
+            bool emit = false;
+            PairGeom g;
+            uint32_t slot = 0, bi = 0;
+            if (p < n_tile_pairs) {
+                uint32_t el = 0;                // the last entry whose first pair is not after p
+#pragma unroll
+                for (uint32_t step = kStageTile / 2; step; step >>= 1) el += (s_prefix[el + step] <= p) ? step : 0u;
+                slot = s_slot[el];
+                bi = p - s_prefix[el];
+                const Vertex cv = slot_store(wb, slot).get(a);
+                const Vertex lv = slot_store(wb, slot).get(depth + (int)bi);
+                const V3 f_cam = pmats.bsdf(sc, cv.info & kVtxMatMask);
+                V3 f_light = mk(0, 0, 0);
+                emit = !(len2(f_cam) <= 0) && pair_geometry(cv, lv, g);                                // camera.h:458-460
+                if (emit) { f_light = pmats.light_factor(sc, lv.info); emit = len2(f_light) > 0; }      // camera.h:462-469
+                if (OWN_TEST && emit) {
+                    GpuTri own = own_tris[lv.tri];
+                    own.material = own_graze[lv.tri];
+                    double t, u, v, det;
+                    if (tri_candidate(own, g.origin, g.dir_unit, 0.001, t, u, v, det) && t <= g.max_t) {
+                        const bool check = nearly_equal(t, g.max_t) || grazes(own, u, v, t, det, gbits);
+                        if (!check || reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t)) emit = false;
                     }
                 }
-                wave_next += (uint64_t)__builtin_popcountll(writers);
+                if (OWN_TEST && emit) {
+                    // With the test above most rays that are made come back clear: what the pair then adds
+                    // (camera.h:471-474) is kept, and k_conn_accum only adds it.  Without the test most rays
+                    // come back blocked, and recomputing the few clear pairs there is cheaper than keeping
+                    // all of them here (0.96 M-triangle lattice: 2 217 against 2 331 Msamples/s).
+                    const V3 c = pair_contribution(cv, lv, g, f_cam, f_light);
+                    double* cb = wb.contrib + (uint64_t)bi * 3u * ns + slot;
+                    cb[0] = c.x; cb[ns] = c.y; cb[2 * ns] = c.z;
+                }
+            }
+            // queue entries for the rays of this round: the wave takes the shadow queue kShadowChunk entries at a time
+            const unsigned long long writers = __ballot(emit);
+            const uint32_t n_new = (uint32_t)__builtin_popcountll(writers);
+            if (n_new) {
+                const uint32_t room = chunk_end - chunk_next;
+                uint32_t fresh = 0;
+                if (n_new > room) {
+                    uint32_t got = 0;
+                    if (lane_id() == 0) got = atomicAdd(shadow_count, kShadowChunk);
+                    fresh = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                }
+                if (emit) {
+                    const uint32_t r = rank_in_mask(writers);
+                    const uint64_t e = r < room ? (uint64_t)(chunk_next + r) : (uint64_t)(fresh + (r - room));
+                    wb.shadow[e] = g.origin.x; wb.shadow[cap + e] = g.origin.y; wb.shadow[2 * cap + e] = g.origin.z;
+                    wb.shadow[3 * cap + e] = g.dir_unit.x; wb.shadow[4 * cap + e] = g.dir_unit.y; wb.shadow[5 * cap + e] = g.dir_unit.z;
+                    wb.shadow[6 * cap + e] = g.max_t;
+                    wb.shadow[7 * cap + e] = __longlong_as_double((long long)(((unsigned long long)slot << 16) | bi));
+                }
+                if (n_new > room) { chunk_next = fresh + (n_new - room); chunk_end = fresh + kShadowChunk; }
+                else chunk_next += n_new;
             }
         }
-        __syncthreads();
+        __syncthreads();        // the tables of this tile are done with
     }
+    // the unused rest of the wave's last piece: entries the traversal skips (negative max_t)
+    for (uint32_t e = chunk_next + lane_id(); e < chunk_end; e += 64u) wb.shadow[6 * cap + e] = -1.0;
     if (STATS) flush_wave_counter(&stats[7], n_pairs);
 }
 
@@ -1434,8 +1446,8 @@ hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBa
 
 hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
                        uint32_t* shadow_count, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    dim3 grid(cfg.stream_blocks), block(kStageBlock);
-    if (cfg.lds_scene) {
+    dim3 grid(cfg.conn_blocks), block(kStageBlock);
+    if (cfg.own_test) {
         // LDS: the reference's tree, then the triangles with their grazing thresholds and leaf nodes
         const size_t shm = cfg.ref_tree_bytes + (size_t)sc.n_tris * (sizeof(GpuTri) + 8);
         if (stats) hipLaunchKernelGGL((k_conn_gen<true, true>), grid, block, shm, st, sc, cam, wb, a, conn_count, shadow_count, stats);
@@ -1449,7 +1461,7 @@ hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers
 
 hipError_t wf_conn_accum(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
                          const WfLaunchCfg& cfg, hipStream_t st) {
-    if (cfg.lds_scene) hipLaunchKernelGGL((k_conn_accum<true>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
+    if (cfg.own_test) hipLaunchKernelGGL((k_conn_accum<true>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
     else hipLaunchKernelGGL((k_conn_accum<false>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
     return hipGetLastError();
 }
