@@ -22,11 +22,11 @@ struct WfBuffers {
     uint32_t* ctr;        // [ns]     random numbers drawn so far by the sample
     double* result;       // [3][ns]  radiance of the sample
     uint32_t* counts;     // [ns]     n_eye | n_light << 12 | flags << 24
-    double* vtx;          // [2*depth][10][ns]  stored (non-delta) path vertices: eye 0.., light depth..
+    double* vtx;          // [ns / kVtxGroup][2*depth][10][kVtxGroup]  stored (non-delta) path vertices: eye 0.., light depth..
     unsigned long long* vis;   // [vis_words][ns]  visibility bits of the pairs (a, b = 0..) of the current eye vertex a
     uint32_t* queue[2];   // [ns]     live-sample queues (ping-pong)
     uint32_t* conn_queue; // [ns]     samples that have both eye and light vertices
-    double* contrib;      // [depth][3][ns]  what pair (a, b) of the current eye vertex a adds if its shadow ray is clear (scenes staged in LDS only)
+    double* contrib;      // [ns / kVtxGroup][depth][3][kVtxGroup]  what pair (a, b) of the current eye vertex a adds if its shadow ray is clear (scenes staged in LDS only)
     double* shadow;       // [8][shadow_cap]  shadow rays: origin, direction, max_t, tag (slot, b)
     uint32_t* counters;   // queue sizes and work-distribution cursors, zeroed once per batch
     const float* ray_len_ptr;  // upper bound of |direction| over the closest-hit rays: *ray_len_ptr, or ray_len when null
@@ -34,7 +34,12 @@ struct WfBuffers {
     uint64_t ns;
     uint64_t shadow_cap;
     uint32_t vis_words;
+    uint32_t vtx_words;       // words of `vtx` per slot (records x 10)
+    uint32_t contrib_words;   // words of `contrib` per slot (depth x 3)
 };
+
+// slots per group of the vertex and contribution arrays (see slot_store in wavefront.hip)
+constexpr uint32_t kVtxGroup = 64;
 
 // wb.hit_tri value of a ray whose closest hit the traversal kernel leaves to the walk over the reference's own tree
 constexpr int32_t kHitRedo = -2;

@@ -85,12 +85,26 @@ BDPT_DEV Rng slot_rng(const GpuCamera& cam, const WfBatch& b, uint32_t slot, uin
     return rng;
 }
 
+// The vertex records of a sample slot.  Slots are kept in groups of kVtxGroup: inside a group the layout is
+// [record][field][slot in group], so the lanes of a wave that read one field of neighbouring slots read neighbouring
+// words, and everything a slot owns lies within one group (tens of KB).  With the fields of ALL slots in one array each
+// - field rows ns words apart - a kernel that reads several records of a slot touches a different page for every
+// field (k_conn_gen: 3.6 address-translation misses per memory instruction).
 BDPT_DEV VertexStore slot_store(const WfBuffers& wb, uint32_t slot) {
     VertexStore st;
-    st.ws = wb.vtx;
-    st.stride = wb.ns;
-    st.g = slot;
+    st.ws = wb.vtx + (uint64_t)(slot / kVtxGroup) * ((uint64_t)kVtxGroup * wb.vtx_words);
+    st.stride = kVtxGroup;
+    st.g = slot % kVtxGroup;
     return st;
+}
+// material and flags of record `rec` (Vertex::info)
+BDPT_DEV uint32_t slot_vertex_info(const WfBuffers& wb, uint32_t slot, int rec) {
+    const VertexStore st = slot_store(wb, slot);
+    return (uint32_t)__double_as_longlong(st.ws[((uint64_t)rec * kVtxDoubles + 9) * st.stride + st.g]);
+}
+// kept contribution of the pair with light vertex `bi` (three words kVtxGroup apart), same grouping
+BDPT_DEV double* slot_contrib(const WfBuffers& wb, uint32_t slot, uint32_t bi) {
+    return wb.contrib + (uint64_t)(slot / kVtxGroup) * ((uint64_t)kVtxGroup * wb.contrib_words) + (uint64_t)bi * 3u * kVtxGroup + slot % kVtxGroup;
 }
 
 // ------------------------------------------------------------------ camera rays
@@ -1008,7 +1022,6 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
     }
     __syncthreads();
     const GrazeBits gbits = graze_bits(sc.bary_margin, 1.0001f);
-    const uint64_t ns = wb.ns;
     const uint32_t count = *conn_count;
     const int depth = cam.max_depth;
     const uint32_t wave = threadIdx.x >> 6;
@@ -1034,7 +1047,7 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
                     if (STATS) n_pairs += n_light;
                     // an eye vertex on an emitter has a zero BSDF (material.h:35-37): every pair it forms
                     // contributes zero whatever the visibility, so no ray is spent on it
-                    const uint32_t info = (uint32_t)__double_as_longlong(wb.vtx[((uint64_t)a * kVtxDoubles + 9) * wb.ns + slot]);
+                    const uint32_t info = slot_vertex_info(wb, slot, a);
                     if (!(info & kVtxIsLight)) mine[j] = n_light;
                 }
             }
@@ -1058,7 +1071,12 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
         const uint32_t n_tile_pairs = s_prefix[kStageTile];
         // pass 2: the pairs of the tile, one per thread and round whatever entry they belong to - the samples of a
         // tile have eye and light subpaths of all lengths, and a loop per entry would leave most lanes of a wave idle
-        // (measured in a Cornell box: 12 of 64 lanes at work)
+        // (measured in a Cornell box: 12 of 64 lanes at work).  Pairs are numbered entry by entry: a wave then works
+        // on a handful of neighbouring samples and uses up the cache lines it touches.  Ordering the entries of the
+        // tile by their number of pairs first (stable counting sort in LDS) - to give a wave one light vertex of 64
+        // samples at a time, or one entry per lane with equally long loops - was slower (k_conn_gen 150 -> 208 and
+        // 195 ms per Cornell-512 frame): the samples a wave touches are then spread over the tile, and the other
+        // words of their cache lines are needed again only after the lines are gone.
         for (uint32_t p0 = 0; p0 < n_tile_pairs; p0 += kStageBlock) {
             const uint32_t p = p0 + threadIdx.x;
             bool emit = false;
@@ -1091,8 +1109,8 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
                     // come back blocked, and recomputing the few clear pairs there is cheaper than keeping
                     // all of them here (0.96 M-triangle lattice: 2 217 against 2 331 Msamples/s).
                     const V3 c = pair_contribution(cv, lv, g, f_cam, f_light);
-                    double* cb = wb.contrib + (uint64_t)bi * 3u * ns + slot;
-                    cb[0] = c.x; cb[ns] = c.y; cb[2 * ns] = c.z;
+                    double* cb = slot_contrib(wb, slot, bi);
+                    cb[0] = c.x; cb[kVtxGroup] = c.y; cb[2 * kVtxGroup] = c.z;
                 }
             }
             // queue entries for the rays of this round: the wave takes the shadow queue kShadowChunk entries at a time
@@ -1145,8 +1163,8 @@ __global__ __launch_bounds__(kBlock) void k_conn_accum(SceneDev sc, GpuCamera ca
             const unsigned long long word = wb.vis[(uint64_t)(bi >> 6) * ns + slot];
             if (!((word >> (bi & 63)) & 1ull)) continue;       // a bit is set only for a pair that had a ray
             if (KEPT) {
-                const double* cb = wb.contrib + (uint64_t)bi * 3u * ns + slot;
-                result = add(result, mk(cb[0], cb[ns], cb[2 * ns]));
+                const double* cb = slot_contrib(wb, slot, (uint32_t)bi);
+                result = add(result, mk(cb[0], cb[kVtxGroup], cb[2 * kVtxGroup]));
             } else {
                 const Vertex lv = slot_store(wb, slot).get(depth + bi);
                 PairGeom g;
