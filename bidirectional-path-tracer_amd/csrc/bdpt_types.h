@@ -68,6 +68,18 @@ struct GpuMaterial {
     int32_t pad;
 };
 
+// What shading a hit needs, in one record per triangle in leaf order (the position a traversal reports): the kernel
+// that shades a hit then makes ONE dependent load where the separate tables (leaf position -> triangle -> normal and
+// material id -> material) make three in a row.
+struct GpuShadeRec {
+    double normal[3];     // unit normal (GpuTriAux::normal)
+    double rgb[3];        // GpuMaterial::rgb
+    double param;         // fuzz of a metal, refraction index of a dielectric
+    uint32_t tri;         // triangle id
+    uint32_t mat;         // material id | type << 30
+};
+static_assert(sizeof(GpuShadeRec) == 64, "GpuShadeRec must stay 64 bytes");
+
 struct GpuCamera {
     double center[3];
     double pixel00[3];
@@ -94,6 +106,8 @@ struct SceneDev {
     uint32_t n_xnodes;
     const GpuTriAux* aux;
     const GpuMaterial* mats;
+    const GpuShadeRec* shade;       // per entry of `stris`
+    const uint32_t* tri_pos;        // per triangle of `tris`: its position in `stris`
     const uint32_t* light_tris;     // the light collection (triangle ids, insertion order)
     const double* light_accum;      // running sums of the areas exactly as triangle.h:212-219 accumulates them
     double light_total_area;

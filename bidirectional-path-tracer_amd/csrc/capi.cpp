@@ -757,7 +757,9 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     size_t off_lacc = off_ltri + align256(h.light_tris.size() * sizeof(uint32_t));
     size_t off_tleaf = off_lacc + align256(h.light_accum.size() * sizeof(double));
     size_t off_tgraze = off_tleaf + align256(h.tri_leaf.size() * sizeof(uint32_t));
-    size_t total = off_tgraze + align256(h.tri_graze.size() * sizeof(int32_t));
+    size_t off_shade = off_tgraze + align256(h.tri_graze.size() * sizeof(int32_t));
+    size_t off_tpos = off_shade + align256(h.shade.size() * sizeof(GpuShadeRec));
+    size_t total = off_tpos + align256(h.tri_pos.size() * sizeof(uint32_t));
     DeviceGuard guard(ctx->device);
     hipError_t e = hipMalloc(&s->d_blob, total);
     if (e != hipSuccess) { delete s; return hip_fail(e, "hipMalloc(scene)"); }
@@ -777,6 +779,8 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
         {off_lacc, h.light_accum.data(), h.light_accum.size() * sizeof(double)},
         {off_tleaf, h.tri_leaf.data(), h.tri_leaf.size() * sizeof(uint32_t)},
         {off_tgraze, h.tri_graze.data(), h.tri_graze.size() * sizeof(int32_t)},
+        {off_shade, h.shade.data(), h.shade.size() * sizeof(GpuShadeRec)},
+        {off_tpos, h.tri_pos.data(), h.tri_pos.size() * sizeof(uint32_t)},
     };
     for (auto& p : parts) {
         e = hipMemcpy(base + p.off, p.src, p.bytes, hipMemcpyHostToDevice);
@@ -795,6 +799,8 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     d.n_xnodes = (uint32_t)h.xnodes.size();
     d.aux = reinterpret_cast<const GpuTriAux*>(base + off_aux);
     d.mats = reinterpret_cast<const GpuMaterial*>(base + off_mats);
+    d.shade = reinterpret_cast<const GpuShadeRec*>(base + off_shade);
+    d.tri_pos = reinterpret_cast<const uint32_t*>(base + off_tpos);
     d.light_tris = reinterpret_cast<const uint32_t*>(base + off_ltri);
     d.light_accum = reinterpret_cast<const double*>(base + off_lacc);
     d.light_total_area = h.light_total_area;

@@ -326,20 +326,46 @@ struct Bounce {
 };
 
 // LAMBERT = false: for scenes without a lambertian triangle (that material's code is the largest part of the function)
+// (the material as the function reads it: from the scene's tables, or from the one record per hit of GpuShadeRec)
+struct ShadeMat {
+    V3 normal, rgb;
+    double fuzz, ior;
+    int32_t type, id;
+};
+template <bool EYE, bool LAMBERT = true>
+BDPT_DEV void shade_bounce(const ShadeMat& m, int32_t tri, V3 o, V3 d, double t_hit, V3 throughput, Rng& rng, Bounce& out);
+
 template <bool EYE, bool LAMBERT = true>
 BDPT_DEV void shade_bounce(const SceneDev& sc, V3 o, V3 d, const HitLite& h, V3 throughput, Rng& rng, Bounce& out) {
     const GpuTriAux ax = sc.aux[h.tri];
     const int32_t mat_id = sc.tris[h.tri].material;
-    const GpuMaterial m = sc.mats[mat_id];
-    V3 p = add(o, scl(h.t, d));                                           // ray.h:21-23
-    V3 outward = ld3(ax.normal);
+    const GpuMaterial gm = sc.mats[mat_id];
+    ShadeMat m;
+    m.normal = ld3(ax.normal); m.rgb = ld3(gm.rgb); m.fuzz = gm.fuzz; m.ior = gm.ior; m.type = gm.type; m.id = mat_id;
+    shade_bounce<EYE, LAMBERT>(m, h.tri, o, d, h.t, throughput, rng, out);
+}
+// the same from the record of leaf position `pos`
+template <bool EYE, bool LAMBERT = true>
+BDPT_DEV void shade_bounce_at(const SceneDev& sc, uint32_t pos, V3 o, V3 d, double t_hit, V3 throughput, Rng& rng, Bounce& out) {
+    const GpuShadeRec r = sc.shade[pos];
+    ShadeMat m;
+    m.normal = ld3(r.normal); m.rgb = ld3(r.rgb); m.fuzz = r.param; m.ior = r.param;
+    m.type = (int32_t)(r.mat >> 30); m.id = (int32_t)(r.mat & kVtxMatMask);
+    shade_bounce<EYE, LAMBERT>(m, (int32_t)r.tri, o, d, t_hit, throughput, rng, out);
+}
+
+template <bool EYE, bool LAMBERT>
+BDPT_DEV void shade_bounce(const ShadeMat& m, int32_t tri, V3 o, V3 d, double t_hit, V3 throughput, Rng& rng, Bounce& out) {
+    const int32_t mat_id = m.id;
+    V3 p = add(o, scl(t_hit, d));                                         // ray.h:21-23
+    V3 outward = m.normal;
     bool front_face = dot(d, outward) < 0;                                // hittable.h:20-26
     V3 normal = front_face ? outward : neg(outward);
 
     out.keep = (m.type == 0 || m.type == 3);
     out.vx.p = p; out.vx.n = normal; out.vx.T = throughput;
     out.vx.info = (uint32_t)mat_id | (m.type == 3 ? kVtxIsLight : 0u) | (front_face ? kVtxFrontFace : 0u);
-    out.vx.tri = (uint32_t)h.tri;
+    out.vx.tri = (uint32_t)tri;
     out.emitted = false;
     out.emitted_term = mk(0, 0, 0);
     out.cont = false;
@@ -347,7 +373,7 @@ BDPT_DEV void shade_bounce(const SceneDev& sc, V3 o, V3 d, const HitLite& h, V3 
 
     if (m.type == 3) {                                                    // diffuse_light: emits, never scatters (material.h:26-28)
         if (EYE && front_face) {
-            V3 e = ld3(m.rgb);
+            V3 e = m.rgb;
             if (len2(e) > 0) { out.emitted_term = mulv(throughput, e); out.emitted = true; }
         }
         return;
@@ -355,7 +381,7 @@ BDPT_DEV void shade_bounce(const SceneDev& sc, V3 o, V3 d, const HitLite& h, V3 
     if (m.type == 1) {                                                    // metal, material.h:73-83, camera.h:355-359
         V3 reflected = reflect(d, normal);
         reflected = add(unit(reflected), scl(m.fuzz, random_unit_vector(rng)));
-        out.T = mulv(throughput, ld3(m.rgb));
+        out.T = mulv(throughput, m.rgb);
         out.d = reflected;
         out.cont = true;
         return;
@@ -385,7 +411,7 @@ BDPT_DEV void shade_bounce(const SceneDev& sc, V3 o, V3 d, const HitLite& h, V3 
     if (pdf_value <= 0) return;
     double cos_theta = dot(normal, su);
     double scattering_pdf = cos_theta < 0 ? 0 : cos_theta / kPi;
-    out.T = divs(scl(scattering_pdf, mulv(throughput, ld3(m.rgb))), pdf_value);
+    out.T = divs(scl(scattering_pdf, mulv(throughput, m.rgb)), pdf_value);
     out.d = scattered;
     out.cont = true;
 }

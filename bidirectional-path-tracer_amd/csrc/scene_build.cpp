@@ -425,6 +425,18 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
             out.sleaf.push_back(node_of[id]);
         }
         out.tri_leaf.swap(node_of);
+        out.shade.resize(out.stris.size());
+        out.tri_pos.assign(n_tri, 0);
+        for (size_t k = 0; k < out.stris.size(); k++) {
+            const uint32_t id = (uint32_t)out.stris[k].pad;
+            const GpuMaterial& m = out.mats[out.tris[id].material];
+            GpuShadeRec& r = out.shade[k];
+            for (int c = 0; c < 3; c++) { r.normal[c] = out.aux[id].normal[c]; r.rgb[c] = m.rgb[c]; }
+            r.param = m.type == 1 ? m.fuzz : m.ior;
+            r.tri = id;
+            r.mat = (uint32_t)out.tris[id].material | ((uint32_t)m.type << 30);
+            out.tri_pos[id] = (uint32_t)k;
+        }
         // Every box contains the boxes below it, coordinate by coordinate (a parent's box is the min/max of its
         // children's, padded outwards at most).  The device relies on it (wavefront.hip: reference_reaches), so it is
         // checked rather than assumed.

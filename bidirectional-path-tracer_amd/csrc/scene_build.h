@@ -18,6 +18,8 @@ struct HostScene {
     std::vector<uint32_t> node_parent;   // parent of every bvh_node (kEndOfTree for the root)
     std::vector<uint32_t> sleaf;         // per entry of `stris`: the bvh_node that holds the triangle; bit 31 = ref_nested
     std::vector<GpuTri> stris;           // triangles in leaf order (pad = original id)
+    std::vector<GpuShadeRec> shade;      // per entry of `stris`: what shading a hit on it needs
+    std::vector<uint32_t> tri_pos;       // per triangle: its position in `stris`
     std::vector<uint32_t> tri_leaf;      // per triangle: the bvh_node that holds it
     std::vector<int32_t> tri_graze;      // per triangle: grazing threshold (high word of a double, see scene_build.cpp)
     std::vector<GpuQuadNode> xnodes;     // closest-hit hierarchy (binned SAH, four children per record)

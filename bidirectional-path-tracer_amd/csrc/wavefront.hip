@@ -744,15 +744,15 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             slots[j] = slot;
             int pi, pj, ps;
             if (!slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
-            const int32_t pos = wb.hit_tri[slot];
-            int32_t tri = pos < 0 ? -1 : sc.stris[pos].pad;      // leaf position -> triangle id
+            int32_t pos = wb.hit_tri[slot];           // position of the hit triangle in the reference's leaf order
             double t_hit = 0.0;
-            if (pos == kHitRedo)
-                tri = redo_closest(sc, mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]),
-                                   mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]), kInf, t_hit);
-            else if (pos >= 0) t_hit = wb.hit[slot];
+            if (pos == kHitRedo) {
+                const int32_t tri = redo_closest(sc, mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]),
+                                                 mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]), kInf, t_hit);
+                pos = tri < 0 ? -1 : (int32_t)sc.tri_pos[tri];
+            } else if (pos >= 0) t_hit = wb.hit[slot];
             V3 T = mk(wb.thr[slot], wb.thr[ns + slot], wb.thr[2 * ns + slot]);
-            if (tri < 0) {
+            if (pos < 0) {
                 if (EYE) {   // camera.h:337-338: background_contrib (0) += throughput * background
                     V3 bg = add(mk(0, 0, 0), mulv(T, ld3(cam.background)));
                     wb.result[slot] = bg.x; wb.result[ns + slot] = bg.y; wb.result[2 * ns + slot] = bg.z;
@@ -761,12 +761,10 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             }
             V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
             V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
-            HitLite h;
-            h.tri = tri; h.t = t_hit; h.u = 0; h.v = 0;
             const uint32_t ctr0 = wb.ctr[slot];
             Rng rng = slot_rng(cam, b, slot, ctr0);
             Bounce bo;
-            shade_bounce<EYE, LAMBERT>(sc, o, d, h, T, rng, bo);
+            shade_bounce_at<EYE, LAMBERT>(sc, (uint32_t)pos, o, d, t_hit, T, rng, bo);
             // state that a bounce leaves as it was is not written again (a specular bounce keeps no vertex, a
             // dielectric one leaves the throughput alone: x * 1.0 is x)
             if (bo.keep && store_vertices) {       // (no vertex store in a scene that cannot form a connection)
