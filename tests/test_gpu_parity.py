@@ -346,6 +346,42 @@ def test_large_scene_uses_global_memory_path(scenes, ctx, oracle):
     sc.close()
 
 
+@pytest.mark.parametrize("big", [False, True])
+def test_more_materials_than_the_connection_stage_keeps_in_lds(scenes, ctx, oracle, big):
+    """The connection stage works out the BSDF values of up to 128 materials once per workgroup; a scene with more
+    reads the material table per pair.  Every triangle here has a material of its own (lambertian, metal and emitters
+    mixed); small = whole scene staged in LDS, big = tables in global memory."""
+    flat = scenes.FlatScene()
+    import random
+    rnd = random.Random(5)
+    def own(kind):
+        if kind == 0: return flat.add_material(scenes.Material(scenes.LAMBERTIAN, (rnd.uniform(.2, .9), rnd.uniform(.2, .9), rnd.uniform(.2, .9))))
+        if kind == 1: return flat.add_material(scenes.Material(scenes.METAL, (rnd.uniform(.5, .9),) * 3, fuzz=rnd.uniform(0, .3)))
+        return flat.add_material(scenes.Material(scenes.DIFFUSE_LIGHT, (rnd.uniform(2, 6),) * 3))
+    n = 12 if big else 9
+    for i in range(n):
+        for j in range(n):
+            kind = 2 if (i * n + j) % 23 == 0 else (1 if (i * n + j) % 7 == 3 else 0)
+            x, z = -3 + 6.0 * i / n, -3 + 6.0 * j / n
+            y = 0.0 if kind != 2 else 3.0
+            flat.add_triangle((x, y, z), (x + 6.0 / n, y, z), (x, y + (0.3 if kind != 2 else 0), z + 6.0 / n), own(kind))
+            flat.add_triangle((x + 6.0 / n, y, z + 6.0 / n), (x, y + (0.3 if kind != 2 else 0), z + 6.0 / n), (x + 6.0 / n, y, z), own(kind))
+    if big:
+        for k in range(3):
+            scenes.add_uv_sphere(flat, (-1.5 + 1.5 * k, 1.0, 0.0), 0.6, own(0), 16, 32)
+    assert len(flat.materials) > 128
+    flat.camera = scenes.Camera(aspect_ratio=1.0, image_width=20, samples_per_pixel=16, max_depth=6,
+                                background=(0.02, 0.03, 0.05), vfov=60, lookfrom=(0, 2.5, -6), lookat=(0, 0.5, 0), vup=(0, 1, 0))
+    sc = ctx.scene(flat)
+    cam = capi.camera_initialize(flat.camera)
+    fb = sc.render(cam, seed=13)
+    ofb, _, _ = oracle.scene(flat).render(cam.as_array(), 20, cam.sqrt_spp, 6, 13, (0, 0, 20, cam.image_height))
+    assert fb.max() > 0
+    assert_bit_equal(fb, ofb, "more than 128 materials, wavefront")
+    assert_bit_equal(sc.render(cam, seed=13, megakernel=True), ofb, "more than 128 materials, single kernel")
+    sc.close()
+
+
 def test_reduce_framebuffer_over_rccl(ctx):
     """bdpt_reduce_framebuffer is one ncclAllReduce(sum, double) on the caller's communicator.  One GPU here, so
     the communicator has one rank and the sum must return the buffer unchanged; wrong arguments are refused."""
