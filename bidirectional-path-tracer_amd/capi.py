@@ -30,6 +30,22 @@ class Material(C.Structure):
                 ("ior", C.c_double)]
 
 
+class PerlinTables(C.Structure):
+    _fields_ = [("randvec", (C.c_double * 3) * 256), ("perm_x", C.c_int32 * 256), ("perm_y", C.c_int32 * 256),
+                ("perm_z", C.c_int32 * 256)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("even", C.c_int32), ("odd", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("reserved", C.c_int32), ("rgb", C.c_double * 3), ("scale", C.c_double), ("data", C.c_void_p)]
+
+
+class SceneObject(C.Structure):
+    _fields_ = [("first_triangle", C.c_uint32), ("n_triangles", C.c_uint32), ("flags", C.c_uint32),
+                ("phase_material", C.c_int32), ("rotate_y_degrees", C.c_double), ("offset", C.c_double * 3),
+                ("density", C.c_double)]
+
+
 class CameraPublic(C.Structure):
     _fields_ = [("lookfrom", C.c_double * 3), ("lookat", C.c_double * 3), ("vup", C.c_double * 3),
                 ("vfov", C.c_double), ("aspect_ratio", C.c_double), ("focus_dist", C.c_double),
@@ -85,7 +101,7 @@ EXPORTED_SYMBOLS = [
     "bdpt_colors_to_rgb8", "bdpt_colors_to_rgb8_device", "bdpt_device_sincos", "bdpt_device_random_doubles",
     "bdpt_device_arith", "bdpt_scene_file_load", "bdpt_scene_file_destroy", "bdpt_scene_file_get", "bdpt_write_png", "bdpt_debug_yaml_to_json",
     "bdpt_reduce_framebuffer", "bdpt_context_set_workspace_limit", "bdpt_context_set_query_walker",
-    "bdpt_render_device_static",
+    "bdpt_render_device_static", "bdpt_scene_create_composite",
 ]
 
 WALKER_PIPELINE = 0          # traversal kernels of the render pipeline (default)
@@ -116,6 +132,8 @@ def load_library() -> C.CDLL:
     lib.bdpt_context_destroy.argtypes = [vp]
     lib.bdpt_camera_initialize.argtypes = [C.POINTER(CameraPublic), C.POINTER(CameraState)]
     lib.bdpt_scene_create.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(Material), C.c_uint32, vp, C.c_uint32, C.POINTER(vp)]
+    lib.bdpt_scene_create_composite.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(Material), C.c_uint32, C.POINTER(Texture), C.c_uint32,
+                                                C.POINTER(SceneObject), C.c_uint32, vp, C.c_uint32, C.POINTER(vp)]
     lib.bdpt_scene_destroy.argtypes = [vp]
     lib.bdpt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
     lib.bdpt_scene_dfs_leaves.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -294,11 +312,54 @@ class Scene:
             mats[i].rgb[:] = [float(c) for c in m.rgb]
             mats[i].fuzz = m.fuzz
             mats[i].ior = m.ior
+            mats[i].reserved = getattr(m, "texture", -1) + 1
         li = flat.light_array()
         h = C.c_void_p()
-        _check(self.lib.bdpt_scene_create(ctx.h, _ptr(v), _ptr(tm), flat.n_triangles, mats, len(flat.materials),
-                                          _ptr(li) if len(li) else None, len(li), C.byref(h)))
+        if hasattr(flat, "objects"):
+            self._create_composite(ctx, flat, v, tm, mats, li, h)
+        else:
+            _check(self.lib.bdpt_scene_create(ctx.h, _ptr(v), _ptr(tm), flat.n_triangles, mats, len(flat.materials),
+                                              _ptr(li) if len(li) else None, len(li), C.byref(h)))
         self.h = h
+
+    def _create_composite(self, ctx, flat, v, tm, mats, li, h):
+        """bdpt_scene_create_composite from a scenes.CompositeScene whose perlin_tables / image_bytes hold what the
+        reference's texture objects hold (one entry per noise / image texture, in texture order)."""
+        texs = (Texture * max(1, len(flat.textures)))()
+        keep = []                                        # buffers the texture records point to
+        n_noise = n_image = 0
+        for i, t in enumerate(flat.textures):
+            texs[i].type = t.type
+            texs[i].even, texs[i].odd = t.even, t.odd
+            texs[i].rgb[:] = [float(c) for c in t.rgb]
+            texs[i].scale = t.scale
+            if t.type == 2:
+                tab = np.ascontiguousarray(flat.perlin_tables[n_noise], dtype=np.float64).ravel()
+                n_noise += 1
+                pt = PerlinTables()
+                C.memmove(pt.randvec, tab[:768].ctypes.data, 768 * 8)
+                perms = np.ascontiguousarray(tab[768:1536].astype(np.int32))
+                C.memmove(pt.perm_x, perms.ctypes.data, 256 * 4)
+                C.memmove(pt.perm_y, perms.ctypes.data + 1024, 256 * 4)
+                C.memmove(pt.perm_z, perms.ctypes.data + 2048, 256 * 4)
+                keep.append(pt)
+                texs[i].data = C.addressof(pt)
+            elif t.type == 3:
+                img = np.ascontiguousarray(flat.image_bytes[n_image], dtype=np.uint8)
+                n_image += 1
+                keep.append(img)
+                texs[i].height, texs[i].width = img.shape[0], img.shape[1]
+                texs[i].data = img.ctypes.data
+        objs = (SceneObject * max(1, len(flat.objects)))()
+        for k, ob in enumerate(flat.objects):
+            objs[k].first_triangle, objs[k].n_triangles, objs[k].flags = ob.first_triangle, ob.n_triangles, ob.flags
+            objs[k].phase_material = ob.phase_material
+            objs[k].rotate_y_degrees = ob.rotate_y_degrees
+            objs[k].offset[:] = [float(c) for c in ob.offset]
+            objs[k].density = ob.density
+        _check(self.lib.bdpt_scene_create_composite(ctx.h, _ptr(v), _ptr(tm), flat.n_triangles, mats, len(flat.materials), texs,
+                                                    len(flat.textures), objs, len(flat.objects), _ptr(li) if len(li) else None,
+                                                    len(li), C.byref(h)))
 
     def close(self):
         if getattr(self, "h", None) and getattr(self.ctx, "h", None):

@@ -13,6 +13,7 @@
 
 #include "../../include/bdpt_amd.h"
 #include "bdpt_types.h"
+#include "composite.h"
 #include "kernels.h"
 #include "scene_build.h"
 #include "static_scratch.h"
@@ -124,6 +125,10 @@ struct bdpt_scene {
     bdpt_context* ctx = nullptr;
     HostScene host;
     SceneDev dev{};
+    // composite scenes (bdpt_scene_create_composite) keep their own tables and run their own kernels
+    bool composite = false;
+    CxHostScene cx_host;
+    CxSceneDev cx_dev{};
     void* d_blob = nullptr;
     size_t blob_bytes = 0;
     uint32_t n_materials = 0;
@@ -224,6 +229,38 @@ int render_megakernel(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_cam
     rl.stats = stats_mode ? ctx->stats : nullptr;
     rl.ws_stride = ws_stride;
     HIP_TRY(launch_render(scene->dev, to_gpu_camera(*cam), rl, (int)grid, stats_mode, unidirectional, stream));
+    return BDPT_OK;
+}
+
+// ---- composite scenes: the same single-kernel scheme over the scene's own tables (composite.hip)
+int render_composite(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, uint64_t seed, const int32_t* rows,
+                     int32_t n_rows, int x0, int x1, int64_t n_owned, double* d_fb, bool stats, hipStream_t stream) {
+    HIP_TRY(hipMemsetAsync(ctx->unit_counter, 0, sizeof(uint32_t), stream));
+    const int spp = cam->sqrt_spp * cam->sqrt_spp;
+    const int ppg = spp >= kBlock ? 1 : kBlock / spp;
+    const int64_t n_units = (n_owned + ppg - 1) / ppg;
+    if (n_units > 0x7FFFFFFF) return fail(BDPT_ERR_INVALID_ARGUMENT, "too many work units in one call");
+    int per_cu = 1;
+    HIP_TRY(cx_render_blocks_per_cu(stats, &per_cu));
+    int64_t grid = (int64_t)ctx->cu_count * per_cu;
+    if (grid > n_units) grid = n_units;
+    const size_t ws_stride = (size_t)grid * kBlock;
+    const size_t slots = 2 * (size_t)(cam->max_depth > 0 ? cam->max_depth : 1);
+    int rc = ensure_vertex_ws(ctx, align256(ws_stride * slots * kCxVtxDoubles * sizeof(double)));
+    if (rc != BDPT_OK) return rc;
+    CxRenderLaunch rl;
+    rl.seed = seed;
+    rl.rows = rows;
+    rl.n_rows = n_rows;
+    rl.x0 = x0; rl.x1 = x1;
+    rl.pixels_per_group = ppg;
+    rl.n_units = (int32_t)n_units;
+    rl.unit_counter = ctx->unit_counter;
+    rl.fb = d_fb;
+    rl.vertex_ws = ctx->vertex_ws;
+    rl.stats = stats ? ctx->stats : nullptr;
+    rl.ws_stride = ws_stride;
+    HIP_TRY(cx_launch_render(scene->cx_dev, to_gpu_camera(*cam), rl, (int)grid, stats, stream));
     return BDPT_OK;
 }
 
@@ -537,7 +574,9 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     // Reference-equivalent counters need the reference's traversal of every shadow ray: that is the single-kernel
     // path, which also takes over when the four-wide hierarchy is deeper than the pipeline's traversal stack.
     // Everything else runs the wavefront pipeline unless the caller asks otherwise.
-    const bool single_kernel = stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || !pipeline_can_walk(scene);
+    const bool single_kernel = scene->composite || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || !pipeline_can_walk(scene);
+    if (scene->composite && unidirectional) return fail(BDPT_ERR_UNSUPPORTED, "BDPT_RENDER_UNIDIRECTIONAL is not available for composite scenes");
+    if (scene->composite && fixed_ws) return fail(BDPT_ERR_UNSUPPORTED, "composite scenes render on the single-kernel path, which allocates");
     if (fixed_ws && (single_kernel || time_stages))
         return fail(BDPT_ERR_UNSUPPORTED, pipeline_can_walk(scene)
                         ? "bdpt_render_device_static supports the flags BDPT_RENDER_COUNT_WORK, BDPT_RENDER_TIME_KERNEL and BDPT_RENDER_UNIDIRECTIONAL only"
@@ -568,7 +607,9 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
         HIP_TRY(wf_fill_rows(rows, y0, y1, shard_rows, shard_count, p->shard_index, stream));
         const int64_t n_owned = n_rows * (x1 - x0);
         int rc;
-        if (single_kernel)
+        if (scene->composite)
+            rc = render_composite(ctx, scene, cam, p->seed, rows, (int32_t)n_rows, x0, x1, n_owned, d_fb, want_stats, stream);
+        else if (single_kernel)
             rc = render_megakernel(ctx, scene, cam, p->seed, rows, (int32_t)n_rows, x0, x1, n_owned, d_fb, stats_mode, unidirectional, stream);
         else
             rc = render_wavefront(ctx, scene, cam, p->seed, rows, x0, x1, n_owned, d_fb, stats_mode, time_stages, unidirectional, stream, fixed_ws, fixed_bytes);
@@ -815,6 +856,91 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     return BDPT_OK;
 }
 
+int bdpt_scene_create_composite(bdpt_context* ctx, const double* tri_vertices, const int32_t* tri_material, uint32_t n_triangles,
+                                const bdpt_material* materials, uint32_t n_materials, const bdpt_texture* textures,
+                                uint32_t n_textures, const bdpt_object* objects, uint32_t n_objects,
+                                const uint32_t* light_triangles, uint32_t n_lights, bdpt_scene** out) {
+    if (!ctx || !out) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (n_objects > 0 && !objects) return fail(BDPT_ERR_INVALID_ARGUMENT, "null object table");
+    DeviceGuard guard(ctx->device);
+    // sin / cos of the rotation angles (hittable.h:79-81) from the device's deterministic routine: the same bits on
+    // every host, and the ones the kernels' own sin / cos would give
+    std::vector<double> radians(n_objects ? n_objects : 1, 0.0), sn(radians.size(), 0.0), cs(radians.size(), 1.0);
+    const double pi = 3.1415926535897932385;                     // src/main.h:20
+    for (uint32_t k = 0; k < n_objects; k++) {
+        radians[k] = objects[k].rotate_y_degrees * pi / 180.0;   // degrees_to_radians, main.h:24-26
+        if ((objects[k].flags & BDPT_OBJECT_ROTATE_Y) && !(std::fabs(radians[k]) <= 1073741824.0))
+            return fail(BDPT_ERR_INVALID_ARGUMENT, "rotation angle out of range");
+    }
+    if (n_objects > 0) {
+        int rc = bdpt_device_sincos(ctx, radians.data(), n_objects, sn.data(), cs.data());
+        if (rc != BDPT_OK) return rc;
+    }
+    bdpt_scene* s = new (std::nothrow) bdpt_scene();
+    if (!s) return fail(BDPT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    s->ctx = ctx;
+    s->composite = true;
+    s->n_materials = n_materials;
+    std::string err;
+    try {
+        err = build_composite_scene(tri_vertices, tri_material, n_triangles, materials, n_materials, textures, n_textures, objects,
+                                    n_objects, sn.data(), cs.data(), light_triangles, n_lights, s->cx_host);
+    } catch (const std::bad_alloc&) {
+        delete s;
+        return fail(BDPT_ERR_OUT_OF_MEMORY, "host allocation failed while building the scene");
+    }
+    if (!err.empty()) { delete s; return fail(BDPT_ERR_INVALID_ARGUMENT, err); }
+
+    const CxHostScene& h = s->cx_host;
+    struct Part { const void* src; size_t bytes; size_t off; };
+    std::vector<CxTexture> tex = h.tex;
+    if (tex.empty()) tex.push_back(CxTexture());
+    std::vector<CxObject> objs = h.objs;
+    if (objs.empty()) objs.push_back(CxObject());
+    std::vector<CxPerlin> perlin = h.perlin;
+    if (perlin.empty()) perlin.resize(1);
+    Part parts[] = {
+        {h.nodes.data(), h.nodes.size() * sizeof(GpuNode), 0},          {h.tris.data(), h.tris.size() * sizeof(GpuTri), 0},
+        {h.aux.data(), h.aux.size() * sizeof(GpuTriAux), 0},            {h.mats.data(), h.mats.size() * sizeof(GpuMaterial), 0},
+        {tex.data(), tex.size() * sizeof(CxTexture), 0},                {objs.data(), objs.size() * sizeof(CxObject), 0},
+        {perlin.data(), perlin.size() * sizeof(CxPerlin), 0},           {h.image_bytes.data(), h.image_bytes.size(), 0},
+        {h.tri_object.data(), h.tri_object.size() * sizeof(int32_t), 0}, {h.light_tris.data(), h.light_tris.size() * sizeof(uint32_t), 0},
+        {h.light_accum.data(), h.light_accum.size() * sizeof(double), 0},
+    };
+    size_t total = 0;
+    for (Part& p : parts) { p.off = total; total += align256(p.bytes); }
+    hipError_t e = hipMalloc(&s->d_blob, total);
+    if (e != hipSuccess) { delete s; return hip_fail(e, "hipMalloc(scene)"); }
+    s->blob_bytes = total;
+    char* base = static_cast<char*>(s->d_blob);
+    for (const Part& p : parts) {
+        e = hipMemcpy(base + p.off, p.src, p.bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return hip_fail(e, "hipMemcpy(scene)"); }
+    }
+    CxSceneDev& d = s->cx_dev;
+    d.nodes = reinterpret_cast<const GpuNode*>(base + parts[0].off);
+    d.tris = reinterpret_cast<const GpuTri*>(base + parts[1].off);
+    d.aux = reinterpret_cast<const GpuTriAux*>(base + parts[2].off);
+    d.mats = reinterpret_cast<const GpuMaterial*>(base + parts[3].off);
+    d.tex = reinterpret_cast<const CxTexture*>(base + parts[4].off);
+    d.objs = reinterpret_cast<const CxObject*>(base + parts[5].off);
+    d.perlin = reinterpret_cast<const CxPerlin*>(base + parts[6].off);
+    d.image_bytes = reinterpret_cast<const uint8_t*>(base + parts[7].off);
+    d.tri_object = reinterpret_cast<const int32_t*>(base + parts[8].off);
+    d.light_tris = reinterpret_cast<const uint32_t*>(base + parts[9].off);
+    d.light_accum = reinterpret_cast<const double*>(base + parts[10].off);
+    d.light_total_area = h.light_total_area;
+    d.n_nodes = (uint32_t)h.nodes.size();
+    d.n_tris = (uint32_t)h.tris.size();
+    d.n_mats = (uint32_t)h.mats.size();
+    d.n_lights = h.n_lights;
+    d.n_objs = (uint32_t)h.objs.size();
+    d.n_tex = (uint32_t)h.tex.size();
+    *out = s;
+    return BDPT_OK;
+}
+
 int bdpt_scene_destroy(bdpt_scene* scene) {
     if (!scene) return BDPT_OK;
     DeviceGuard guard(scene->ctx->device);
@@ -826,6 +952,16 @@ int bdpt_scene_destroy(bdpt_scene* scene) {
 
 int bdpt_scene_get_info(const bdpt_scene* scene, bdpt_scene_info* out) {
     if (!scene || !out) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    if (scene->composite) {
+        out->n_triangles = scene->cx_dev.n_tris;
+        out->n_materials = scene->cx_dev.n_mats;
+        out->n_lights = scene->cx_dev.n_lights;
+        out->n_nodes = scene->cx_dev.n_nodes;
+        out->max_depth = scene->cx_host.tree_depth;
+        out->reserved = 0;
+        out->device_bytes = scene->blob_bytes;
+        return BDPT_OK;
+    }
     out->n_triangles = scene->dev.n_tris;
     out->n_materials = scene->dev.n_mats;
     out->n_lights = scene->dev.n_lights;
@@ -838,6 +974,12 @@ int bdpt_scene_get_info(const bdpt_scene* scene, bdpt_scene_info* out) {
 
 int bdpt_scene_dfs_leaves(const bdpt_scene* scene, uint32_t* out, uint32_t capacity, uint32_t* count) {
     if (!scene || !count) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    if (scene->composite) {
+        const std::vector<int32_t>& w = scene->cx_host.world_leaves;
+        *count = (uint32_t)w.size();
+        if (out) for (uint32_t i = 0; i < w.size() && i < capacity; i++) out[i] = (uint32_t)w[i];
+        return BDPT_OK;
+    }
     const std::vector<uint32_t>& v = scene->host.dfs_leaves;
     *count = (uint32_t)v.size();
     if (out) for (uint32_t i = 0; i < v.size() && i < capacity; i++) out[i] = v[i];
@@ -846,7 +988,7 @@ int bdpt_scene_dfs_leaves(const bdpt_scene* scene, uint32_t* out, uint32_t capac
 
 int bdpt_scene_node_boxes(const bdpt_scene* scene, double* out, uint32_t capacity_nodes) {
     if (!scene || !out) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
-    const std::vector<GpuNode>& n = scene->host.nodes;
+    const std::vector<GpuNode>& n = scene->composite ? scene->cx_host.nodes : scene->host.nodes;
     if (capacity_nodes < n.size()) return fail(BDPT_ERR_INVALID_ARGUMENT, "output buffer too small");
     for (size_t i = 0; i < n.size(); i++)
         for (int k = 0; k < 3; k++) { out[6 * i + 2 * k] = n[i].lo[k]; out[6 * i + 2 * k + 1] = n[i].hi[k]; }
@@ -859,6 +1001,11 @@ int bdpt_trace_closest_device(bdpt_context* ctx, const bdpt_scene* scene, const 
     if (scene->ctx != ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "scene belongs to another context");
     if (n == 0) return BDPT_OK;
     DeviceGuard guard(ctx->device);
+    if (scene->composite) {
+        HIP_TRY(cx_launch_trace_closest(scene->cx_dev, static_cast<const double*>(d_rays), n, static_cast<double*>(d_hits), nullptr,
+                                        static_cast<hipStream_t>(stream)));
+        return BDPT_OK;
+    }
     if (ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene))
         return trace_closest_pipeline(ctx, scene, static_cast<const double*>(d_rays), n, static_cast<double*>(d_hits),
                                       static_cast<hipStream_t>(stream));
@@ -883,7 +1030,9 @@ int bdpt_trace_closest(bdpt_context* ctx, const bdpt_scene* scene, const double*
         if ((e = hipMemcpy(d_rays, rays, n * 8 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
         if (stats && (e = hipMemset(ctx->stats, 0, sizeof(unsigned long long) * kStatWords)) != hipSuccess) break;
         // counters have the reference's meaning, so a counting call walks the reference's own tree
-        if (!stats && ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene)) {
+        if (scene->composite) {
+            if ((e = cx_launch_trace_closest(scene->cx_dev, d_rays, n, d_hits, stats ? ctx->stats : nullptr, nullptr)) != hipSuccess) break;
+        } else if (!stats && ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene)) {
             rc = trace_closest_pipeline(ctx, scene, d_rays, n, d_hits, nullptr);
             if (rc != BDPT_OK) break;
         } else if ((e = launch_trace_closest(scene->dev, d_rays, n, d_hits, stats ? ctx->stats : nullptr, nullptr)) != hipSuccess) break;
@@ -913,7 +1062,9 @@ int bdpt_visible(bdpt_context* ctx, const bdpt_scene* scene, const double* pairs
     int rc = BDPT_OK;
     do {
         if ((e = hipMemcpy(d_pairs, pairs, n * 6 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
-        if (ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene)) {
+        if (scene->composite) {
+            if ((e = cx_launch_visible(scene->cx_dev, d_pairs, n, d_out, nullptr)) != hipSuccess) break;
+        } else if (ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene)) {
             rc = visible_pipeline(ctx, scene, d_pairs, n, d_out, nullptr);
             if (rc != BDPT_OK) break;
         } else if ((e = launch_visible(scene->dev, d_pairs, n, d_out, nullptr)) != hipSuccess) break;

@@ -1,4 +1,4 @@
-// Deterministic sin/cos/x^5 for the device path.
+// Deterministic sin/cos/x^5/log for the device path.
 //
 // The reference calls libm's cos/sin on phi = 2*pi*r1 (src/core/vec3.h:153-155) and
 // pow(1 - cosine, 5) (src/materials/material.h:129).  Device math libraries and glibc round
@@ -90,7 +90,8 @@ __device__ static const double kCosC[15][2] = {
     { 0x1.0a18a2635085dp-98,  0x1.b9e2e28e1aa54p-153 },
 };
 
-// sin and cos of x, 0 <= x <= 8.
+// sin and cos of x, |x| <= 2^30 (pi/2 is carried to 2^-164: the reduced argument keeps ~100 good bits for every
+// such x).  Callers: random_cosine_direction (0 <= x < 2 pi), noise textures and rotation angles (any sign).
 __device__ __forceinline__ void det_sincos(double x, double& s_out, double& c_out) {
     double kd = __builtin_rint(x * 0x1.45f306dc9c883p-1);     // nearest integer to x * 2/pi
     int k = (int)kd;
@@ -144,6 +145,82 @@ __device__ __forceinline__ double det_pow5(double x) {
     dd x4 = dd_mul(x2, x2);
     dd x5 = dd_mul_d(x4, x);
     return x5.hi;
+}
+
+// 1/(2k+1), k = 0..21, as (hi, lo) pairs
+__device__ static const double kOddRec[22][2] = {
+    { 0x1.0000000000000p+0, 0x0.0p+0 },
+    { 0x1.5555555555555p-2, 0x1.5555555555555p-56 },
+    { 0x1.999999999999ap-3, -0x1.999999999999ap-57 },
+    { 0x1.2492492492492p-3, 0x1.2492492492492p-57 },
+    { 0x1.c71c71c71c71cp-4, 0x1.c71c71c71c71cp-58 },
+    { 0x1.745d1745d1746p-4, -0x1.745d1745d1746p-59 },
+    { 0x1.3b13b13b13b14p-4, -0x1.3b13b13b13b14p-58 },
+    { 0x1.1111111111111p-4, 0x1.1111111111111p-60 },
+    { 0x1.e1e1e1e1e1e1ep-5, 0x1.e1e1e1e1e1e1ep-61 },
+    { 0x1.af286bca1af28p-5, 0x1.af286bca1af28p-59 },
+    { 0x1.8618618618618p-5, 0x1.8618618618618p-59 },
+    { 0x1.642c8590b2164p-5, 0x1.642c8590b2164p-60 },
+    { 0x1.47ae147ae147bp-5, -0x1.eb851eb851eb8p-61 },
+    { 0x1.2f684bda12f68p-5, 0x1.2f684bda12f68p-59 },
+    { 0x1.1a7b9611a7b96p-5, 0x1.1a7b9611a7b96p-61 },
+    { 0x1.0842108421084p-5, 0x1.0842108421084p-60 },
+    { 0x1.f07c1f07c1f08p-6, -0x1.f07c1f07c1f08p-61 },
+    { 0x1.d41d41d41d41dp-6, 0x1.0750750750750p-60 },
+    { 0x1.bacf914c1bad0p-6, -0x1.bacf914c1bad0p-60 },
+    { 0x1.a41a41a41a41ap-6, 0x1.0690690690690p-60 },
+    { 0x1.8f9c18f9c18fap-6, -0x1.f3831f3831f38p-61 },
+    { 0x1.7d05f417d05f4p-6, 0x1.7d05f417d05f4p-62 },
+};
+
+__device__ __forceinline__ dd dd_div(dd a, dd b) {
+    double q1 = a.hi / b.hi;
+    dd r = dd_add(a, dd_mul_d(b, -q1));
+    double q2 = r.hi / b.hi;
+    r = dd_add(r, dd_mul_d(b, -q2));
+    double q3 = r.hi / b.hi;
+    dd q = fast_two_sum(q1, q2);
+    dd t; t.hi = q3; t.lo = 0.0;
+    return dd_add(q, t);
+}
+
+// Natural logarithm of a positive finite x (stands in for the std::log of
+// src/materials/volumes/constant_medium.h:40).  x = m 2^e, sqrt(1/2) <= m < sqrt(2); log m = 2 atanh(s) with
+// s = (m - 1)/(m + 1), 22 terms in double-double; e ln 2 from a three-part ln 2 whose first part has 42 bits.
+// The steps are kept out of line: the function is called once per medium crossing, not per ray step.
+__device__ __noinline__ double det_log(double x) {
+    if (x != x || x < 0.0) return __builtin_nan("");
+    if (x == 0.0) return -__builtin_huge_val();
+    if (x == __builtin_huge_val()) return x;
+    int e = 0;
+    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    if (((bits >> 52) & 0x7ffull) == 0) {          // subnormal: scale into the normal range first
+        x = x * 0x1p54;
+        bits = (unsigned long long)__double_as_longlong(x);
+        e = -54;
+    }
+    e += (int)((bits >> 52) & 0x7ffull) - 1022;
+    double m = __longlong_as_double((long long)((bits & 0x800fffffffffffffull) | 0x3fe0000000000000ull));    // 0.5 <= m < 1
+    if (m < 0x1.6a09e667f3bcdp-1) { m = m * 2.0; e = e - 1; }
+    const double f = m - 1.0;                      // exact
+    dd num; num.hi = f; num.lo = 0.0;
+    dd den = two_sum(2.0, f);
+    dd s = dd_div(num, den);
+    dd z = dd_mul(s, s);
+    dd acc; acc.hi = kOddRec[21][0]; acc.lo = kOddRec[21][1];
+    for (int k = 20; k >= 0; k--) {
+        dd c; c.hi = kOddRec[k][0]; c.lo = kOddRec[k][1];
+        acc = dd_add(c, dd_mul(acc, z));
+    }
+    dd lm = dd_mul(acc, s);
+    lm.hi = lm.hi * 2.0; lm.lo = lm.lo * 2.0;
+    const double L1 = 0x1.62e42fefa3800p-1, L2 = 0x1.ef35793c76730p-45, L3 = 0x1.f97b57a079a19p-103;
+    const double ed = (double)e;
+    dd t1; t1.hi = ed * L1; t1.lo = 0.0;           // exact
+    dd t2 = two_prod(ed, L2);
+    t2.lo = t2.lo + ed * L3;
+    dd r = dd_add(dd_add(t1, t2), lm);
+    return r.hi;
 }
 
 }  // namespace bdpt

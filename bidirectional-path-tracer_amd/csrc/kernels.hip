@@ -193,6 +193,7 @@ __global__ void arith_kernel(int op, const double* a, const double* b, uint64_t 
         case 4: r = __builtin_fmin(a[i], b[i]); break;
         case 5: r = __builtin_fmax(a[i], b[i]); break;
         case 6: r = det_pow5(a[i]); break;
+        case 8: r = det_log(a[i]); break;
         default: r = 1.0 / a[i]; break;
     }
     out[i] = r;

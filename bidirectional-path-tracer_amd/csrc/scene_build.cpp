@@ -1,6 +1,7 @@
 // Host-side scene preparation (plain C++, no device code).  Built with -ffp-contract=off: the
 // triangle precompute and the box unions must round like the reference's.
 #include "scene_build.h"
+#include "composite.h"
 
 #include <algorithm>
 #include <cmath>
@@ -538,6 +539,275 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
         out.light_accum[i] = accum;
     }
     out.light_total_area = accum;
+    return std::string();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Composite scenes (composite.h)
+namespace {
+
+// triangle::triangle, src/objects/primatives/triangle.h:21-39
+void precompute_triangle(const double* v0, int32_t material, GpuTri& t, GpuTriAux& a, Box3& box) {
+    const double* v1 = v0 + 3;
+    const double* v2 = v0 + 6;
+    for (int k = 0; k < 3; k++) {
+        t.v0[k] = v0[k];
+        t.e1[k] = v1[k] - v0[k];
+        t.e2[k] = v2[k] - v0[k];
+    }
+    t.material = material;
+    t.pad = 0;
+    const double nx = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1];
+    const double ny = t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2];
+    const double nz = t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0];
+    const double nlen = std::sqrt(nx * nx + ny * ny + nz * nz);
+    const double inv = 1 / nlen;
+    a.normal[0] = inv * nx; a.normal[1] = inv * ny; a.normal[2] = inv * nz;
+    a.area = 0.5 * nlen;
+    for (int k = 0; k < 3; k++) {
+        const double lo = second_fmin(v0[k], second_fmin(v1[k], v2[k]));
+        const double hi = second_fmax(v0[k], second_fmax(v1[k], v2[k]));
+        if (lo <= hi) { box.lo[k] = lo; box.hi[k] = hi; }
+        else { box.lo[k] = hi; box.hi[k] = lo; }
+    }
+}
+
+// One bvh_node tree in pre-order -> threaded records appended to `out`.  item_ref[i]: the leaf reference of list
+// entry i (triangle id, or -(object + 2)).  `leaves` receives the references in visiting order.
+void append_threaded(const std::vector<BuildNode>& bn, const std::vector<int32_t>& item_ref, std::vector<GpuNode>& out,
+                     uint32_t& tree_depth, std::vector<int32_t>* leaves) {
+    const uint32_t base = (uint32_t)out.size();
+    const uint32_t n = (uint32_t)bn.size();
+    std::vector<uint32_t> subtree_end(n), depth(n, 1);
+    for (int64_t i = (int64_t)n - 1; i >= 0; i--) subtree_end[i] = (bn[i].left >= 0) ? subtree_end[bn[i].right] : (uint32_t)i + 1;
+    for (uint32_t i = 0; i < n; i++) {
+        GpuNode g;
+        for (int k = 0; k < 3; k++) { g.lo[k] = bn[i].box.lo[k]; g.hi[k] = bn[i].box.hi[k]; }
+        const uint32_t end = subtree_end[i];
+        g.skip = (end >= n) ? kEndOfTree : base + end;
+        if (bn[i].left >= 0) {
+            g.next = base + (uint32_t)bn[i].left;
+            g.tri0 = g.tri1 = -1;
+            depth[bn[i].left] = depth[bn[i].right] = depth[i] + 1;
+            if (depth[i] + 1 > tree_depth) tree_depth = depth[i] + 1;
+        } else {
+            g.next = g.skip;
+            g.tri0 = item_ref[(uint32_t)~bn[i].left];
+            g.tri1 = item_ref[(uint32_t)~bn[i].right];
+            if (leaves) { leaves->push_back(g.tri0); leaves->push_back(g.tri1); }
+        }
+        out.push_back(g);
+    }
+}
+
+// every texture reachable from `t` (through checker children)
+bool reaches_image(const std::vector<CxTexture>& tex, int32_t t) {
+    if (tex[t].type == BDPT_TEX_IMAGE) return true;
+    if (tex[t].type == BDPT_TEX_CHECKER) return reaches_image(tex, tex[t].a) || reaches_image(tex, tex[t].b);
+    return false;
+}
+
+}  // namespace
+
+std::string build_composite_scene(const double* tv, const int32_t* tri_material, uint32_t n_tri, const bdpt_material* materials,
+                                  uint32_t n_mat, const bdpt_texture* textures, uint32_t n_tex, const bdpt_object* objects,
+                                  uint32_t n_obj, const double* sin_theta, const double* cos_theta,
+                                  const uint32_t* light_triangles, uint32_t n_lights, CxHostScene& out) {
+    if (!tv || !tri_material || !materials) return "null table pointer";
+    if (n_tri == 0) return "scene has no triangles";
+    if (n_tri >= (1u << 29)) return "too many triangles";
+    if (n_mat == 0) return "scene has no materials";
+    if (n_tex > 0 && !textures) return "null texture table";
+    if (n_obj > 0 && (!objects || !sin_theta || !cos_theta)) return "null object table";
+    if (n_lights > 0 && !light_triangles) return "null light list";
+    out = CxHostScene();
+
+    // textures, src/materials/textures/texture.h
+    out.tex.resize(n_tex);
+    for (uint32_t i = 0; i < n_tex; i++) {
+        const bdpt_texture& t = textures[i];
+        CxTexture& c = out.tex[i];
+        c = CxTexture();
+        c.type = t.type;
+        for (int k = 0; k < 3; k++) c.rgb[k] = t.rgb[k];
+        switch (t.type) {
+            case BDPT_TEX_SOLID: break;
+            case BDPT_TEX_CHECKER:
+                // children are constructed before the texture that holds them (texture.h:30-34)
+                if (t.even < 0 || t.odd < 0 || (uint32_t)t.even >= i || (uint32_t)t.odd >= i) return "checker texture: sub-texture index must be smaller than its own";
+                c.scale = 1.0 / t.scale;                       // inv_scale, texture.h:31
+                c.a = t.even; c.b = t.odd;
+                break;
+            case BDPT_TEX_NOISE: {
+                if (!t.data) return "noise texture without perlin tables";
+                const bdpt_perlin_tables* p = static_cast<const bdpt_perlin_tables*>(t.data);
+                CxPerlin cp;
+                std::memcpy(cp.randvec, p->randvec, sizeof cp.randvec);
+                std::memcpy(cp.perm_x, p->perm_x, sizeof cp.perm_x);
+                std::memcpy(cp.perm_y, p->perm_y, sizeof cp.perm_y);
+                std::memcpy(cp.perm_z, p->perm_z, sizeof cp.perm_z);
+                for (int k = 0; k < 256; k++)
+                    if ((uint32_t)cp.perm_x[k] > 255u || (uint32_t)cp.perm_y[k] > 255u || (uint32_t)cp.perm_z[k] > 255u) return "perlin permutation entry out of range";
+                c.scale = t.scale;
+                c.data = (uint32_t)out.perlin.size();
+                out.perlin.push_back(cp);
+                break;
+            }
+            case BDPT_TEX_IMAGE: {
+                c.a = t.width; c.b = t.height;
+                if (t.height > 0) {
+                    if (t.width <= 0 || !t.data) return "image texture without pixel data";
+                    const size_t bytes = (size_t)t.width * (size_t)t.height * 3;
+                    if (out.image_bytes.size() + bytes >= ((size_t)1 << 32)) return "image textures too large";
+                    c.data = (uint32_t)out.image_bytes.size();
+                    const uint8_t* src = static_cast<const uint8_t*>(t.data);
+                    out.image_bytes.insert(out.image_bytes.end(), src, src + bytes);
+                }
+                break;
+            }
+            default: return "unknown texture type";
+        }
+    }
+    if (out.image_bytes.empty()) out.image_bytes.push_back(0);
+
+    out.mats.resize(n_mat);
+    for (uint32_t i = 0; i < n_mat; i++) {
+        const bdpt_material& m = materials[i];
+        if (m.type < BDPT_LAMBERTIAN || m.type > BDPT_ISOTROPIC) return "unknown material type";
+        if (m.reserved < 0 || (uint32_t)m.reserved > n_tex) return "material texture index out of range";
+        if (m.reserved > 0 && (m.type == BDPT_METAL || m.type == BDPT_DIELECTRIC)) return "metal and dielectric take no texture";
+        if (m.type == BDPT_ISOTROPIC && m.reserved > 0 && reaches_image(out.tex, m.reserved - 1))
+            return "isotropic material with an image texture: the reference reads unset texture coordinates there";
+        GpuMaterial g;
+        g.rgb[0] = m.rgb[0]; g.rgb[1] = m.rgb[1]; g.rgb[2] = m.rgb[2];
+        g.fuzz = m.fuzz < 1 ? m.fuzz : 1;
+        g.ior = m.ior;
+        g.type = m.type;
+        g.pad = m.reserved;
+        out.mats[i] = g;
+    }
+
+    // triangles; which object each belongs to
+    out.tris.resize(n_tri);
+    out.aux.resize(n_tri);
+    out.tri_object.assign(n_tri, -1);
+    std::vector<BuildTri> btris(n_tri);
+    for (uint32_t i = 0; i < n_tri; i++) {
+        if (tri_material[i] < 0 || (uint32_t)tri_material[i] >= n_mat) return "triangle material index out of range";
+        if (materials[tri_material[i]].type == BDPT_ISOTROPIC) return "isotropic is the phase function of a medium, not a surface material";
+        precompute_triangle(tv + 9 * (size_t)i, tri_material[i], out.tris[i], out.aux[i], btris[i].box);
+    }
+    uint32_t next_free = 0;
+    for (uint32_t k = 0; k < n_obj; k++) {
+        const bdpt_object& ob = objects[k];
+        if (ob.n_triangles == 0) return "object without triangles";
+        if (ob.first_triangle < next_free || (uint64_t)ob.first_triangle + ob.n_triangles > n_tri) return "object triangle ranges must be ascending, disjoint and inside the triangle array";
+        next_free = ob.first_triangle + ob.n_triangles;
+        for (uint32_t i = 0; i < ob.n_triangles; i++) out.tri_object[ob.first_triangle + i] = (int32_t)k;
+        if (ob.flags & ~(kCxRotate | kCxTranslate | kCxMedium)) return "unknown object flag";
+        if (ob.flags & kCxMedium) {
+            if (ob.phase_material < 0 || (uint32_t)ob.phase_material >= n_mat || materials[ob.phase_material].type != BDPT_ISOTROPIC)
+                return "medium without an isotropic phase material";
+        }
+    }
+
+    // each object's own bvh_node(hittable_list of its triangles), and its box in the world
+    std::vector<std::vector<BuildNode>> obj_nodes(n_obj);
+    std::vector<Box3> obj_box(n_obj);
+    out.objs.resize(n_obj);
+    for (uint32_t k = 0; k < n_obj; k++) {
+        const bdpt_object& ob = objects[k];
+        std::vector<BuildTri> local(btris.begin() + ob.first_triangle, btris.begin() + ob.first_triangle + ob.n_triangles);
+        Builder b(local);
+        b.order.resize(ob.n_triangles);
+        for (uint32_t i = 0; i < ob.n_triangles; i++) b.order[i] = i;
+        b.build(0, ob.n_triangles);
+        Box3 box = b.nodes[0].box;                              // bvh_node::bounding_box
+        CxObject& co = out.objs[k];
+        co = CxObject();
+        co.flags = ob.flags;
+        co.phase_material = (ob.flags & kCxMedium) ? ob.phase_material : -1;
+        co.neg_inv_density = (ob.flags & kCxMedium) ? -1 / ob.density : 0.0;      // constant_medium.h:11
+        co.sin_theta = sin_theta[k]; co.cos_theta = cos_theta[k];
+        for (int a = 0; a < 3; a++) co.offset[a] = ob.offset[a];
+        if (ob.flags & kCxRotate) {                             // rotate_y::rotate_y, hittable.h:82-107
+            const double inf = std::numeric_limits<double>::infinity();
+            double mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+            for (int i = 0; i < 2; i++)
+                for (int j = 0; j < 2; j++)
+                    for (int q = 0; q < 2; q++) {
+                        const double x = i * box.hi[0] + (1 - i) * box.lo[0];
+                        const double y = j * box.hi[1] + (1 - j) * box.lo[1];
+                        const double z = q * box.hi[2] + (1 - q) * box.lo[2];
+                        const double newx = co.cos_theta * x + co.sin_theta * z;
+                        const double newz = -co.sin_theta * x + co.cos_theta * z;
+                        const double tester[3] = {newx, y, newz};
+                        for (int c = 0; c < 3; c++) {
+                            mn[c] = second_fmin(mn[c], tester[c]);
+                            mx[c] = second_fmax(mx[c], tester[c]);
+                        }
+                    }
+            for (int c = 0; c < 3; c++) {                       // aabb(point, point), aabb.h:18-25: no padding
+                if (mn[c] <= mx[c]) { box.lo[c] = mn[c]; box.hi[c] = mx[c]; }
+                else { box.lo[c] = mx[c]; box.hi[c] = mn[c]; }
+            }
+        }
+        if (ob.flags & kCxTranslate) {                          // bbox + offset, aabb.h:95-97 -> aabb(interval x3) pads
+            for (int c = 0; c < 3; c++) {
+                box.lo[c] = box.lo[c] + ob.offset[c];
+                box.hi[c] = box.hi[c] + ob.offset[c];
+                pad_axis(box.lo[c], box.hi[c]);
+            }
+        }
+        obj_box[k] = box;
+        obj_nodes[k].swap(b.nodes);
+        // the builder sorted local indices; leaf references become global triangle ids below
+    }
+
+    // the world's list: triangles of no object and the objects, in the order of the triangle array
+    std::vector<BuildTri> items;
+    std::vector<int32_t> item_ref;
+    for (uint32_t i = 0; i < n_tri;) {
+        const int32_t k = out.tri_object[i];
+        BuildTri it;
+        if (k < 0) { it.box = btris[i].box; items.push_back(it); item_ref.push_back((int32_t)i); i++; }
+        else { it.box = obj_box[k]; items.push_back(it); item_ref.push_back(-((int32_t)k + 2)); i += objects[k].n_triangles; }
+    }
+    Builder wb(items);
+    wb.order.resize(items.size());
+    for (size_t i = 0; i < items.size(); i++) wb.order[i] = (uint32_t)i;
+    wb.build(0, items.size());
+
+    out.tree_depth = 1;
+    append_threaded(wb.nodes, item_ref, out.nodes, out.tree_depth, &out.world_leaves);
+    out.n_world_nodes = (uint32_t)out.nodes.size();
+    for (uint32_t k = 0; k < n_obj; k++) {
+        std::vector<int32_t> refs(objects[k].n_triangles);
+        for (uint32_t i = 0; i < objects[k].n_triangles; i++) refs[i] = (int32_t)(objects[k].first_triangle + i);
+        out.objs[k].root = (uint32_t)out.nodes.size();
+        uint32_t d = 1;
+        append_threaded(obj_nodes[k], refs, out.nodes, d, nullptr);
+    }
+
+    // the light collection: triangles of the world's list only
+    if (n_lights == 0) {
+        for (uint32_t i = 0; i < n_tri; i++) if (out.tri_object[i] < 0) out.light_tris.push_back(i);
+    } else {
+        out.light_tris.assign(light_triangles, light_triangles + n_lights);
+        for (uint32_t id : out.light_tris) {
+            if (id >= n_tri) return "light triangle index out of range";
+            if (out.tri_object[id] >= 0) return "light triangles must not belong to an object";
+        }
+    }
+    out.light_accum.resize(out.light_tris.size());
+    double accum = 0.0;
+    for (size_t i = 0; i < out.light_tris.size(); i++) {
+        accum += out.aux[out.light_tris[i]].area;
+        out.light_accum[i] = accum;
+    }
+    out.light_total_area = accum;
+    out.n_lights = (uint32_t)out.light_tris.size();
+    if (out.light_tris.empty()) { out.light_tris.push_back(0); out.light_accum.push_back(0.0); out.light_total_area = 0.0; }
     return std::string();
 }
 

@@ -21,7 +21,9 @@ from typing import List, Sequence
 
 import numpy as np
 
-LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT = 0, 1, 2, 3
+LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT, ISOTROPIC = 0, 1, 2, 3, 4
+TEX_SOLID, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = 0, 1, 2, 3
+OBJECT_ROTATE_Y, OBJECT_TRANSLATE, OBJECT_MEDIUM = 1, 2, 4
 
 # /root/reference/src/main.h:20
 PI = 3.1415926535897932385
@@ -33,6 +35,7 @@ class Material:
     rgb: Sequence[float] = (0.0, 0.0, 0.0)
     fuzz: float = 0.0
     ior: float = 1.5
+    texture: int = -1      # composite scenes: index of the texture that replaces `rgb` (-1: the solid colour)
 
 
 @dataclass
@@ -207,6 +210,200 @@ def add_uv_sphere(scene: FlatScene, center, radius: float, mat: int, lat_steps: 
             if lat < lat_steps - 1:
                 scene.add_triangle(p00, p11, p01, mat)
 
+
+
+# ------------------------------------------------------------------------------- composite scenes
+@dataclass
+class Texture:
+    """/root/reference/src/materials/textures/texture.h:14-87"""
+    type: int
+    rgb: Sequence[float] = (0.0, 0.0, 0.0)     # solid
+    scale: float = 1.0                         # checker, noise
+    even: int = -1                             # checker: indices of earlier textures
+    odd: int = -1
+    image: object = None                       # image: H x W x 3 uint8 array as FILE content (the reference's loader
+                                               # turns it into its own bytes, rtw_stb_image.h:98-112)
+
+
+@dataclass
+class SceneObject:
+    """One entry of the world's list that is a mesh of its own: translate(rotate_y(bvh_node(mesh))), optionally the
+    boundary of a constant_medium (/root/reference/src/objects/hittable.h:46-157,
+    /root/reference/src/materials/volumes/constant_medium.h)."""
+    first_triangle: int
+    n_triangles: int
+    flags: int = 0
+    rotate_y_degrees: float = 0.0
+    offset: Sequence[float] = (0.0, 0.0, 0.0)
+    density: float = 0.0
+    phase_material: int = -1
+
+
+@dataclass
+class CompositeScene(FlatScene):
+    textures: List[Texture] = field(default_factory=list)
+    objects: List[SceneObject] = field(default_factory=list)
+    # filled from the reference harness (tests/golden) or by the host: what the reference's objects hold
+    perlin_tables: List[np.ndarray] = field(default_factory=list)   # per noise texture, 1536 doubles (randvec, perms)
+    image_bytes: List[np.ndarray] = field(default_factory=list)     # per image texture, H x W x 3 uint8 (rtw_image::bdata)
+
+    def add_texture(self, t: Texture) -> int:
+        self.textures.append(t)
+        return len(self.textures) - 1
+
+    def begin_object(self) -> int:
+        return self.n_triangles
+
+    def end_object(self, first: int, **kw) -> int:
+        """Triangles added since begin_object() become one object (they are NOT light triangles)."""
+        self.lights = [l for l in self.lights if l < first]
+        self.objects.append(SceneObject(first, self.n_triangles - first, **kw))
+        return len(self.objects) - 1
+
+    def to_bytes(self) -> bytes:
+        out = [b"BDPTSCN1", struct.pack("<4I", len(self.materials), self.n_triangles, len(self.lights), 0)]
+        for m in self.materials:
+            out.append(struct.pack("<2i5d", m.type, m.texture + 1, m.rgb[0], m.rgb[1], m.rgb[2], m.fuzz, m.ior))
+        rec = np.zeros(self.n_triangles, dtype=[("v", "<f8", 9), ("m", "<i4"), ("pad", "<i4")])
+        rec["v"] = self.vertex_array()
+        rec["m"] = self.tri_material_array()
+        out.append(rec.tobytes())
+        lights = list(self.lights) + ([0] if len(self.lights) % 2 else [])
+        out.append(struct.pack("<%dI" % len(lights), *lights))
+        c = self.camera
+        out.append(struct.pack("<16d4i", *c.lookfrom, *c.lookat, *c.vup, c.vfov, c.aspect_ratio, c.focus_dist,
+                               c.defocus_angle, *c.background, c.image_width, c.samples_per_pixel, c.max_depth, 0))
+        out.append(b"BDPTEXT1" + struct.pack("<4I", len(self.textures), len(self.objects), 0, 0))
+        for t in self.textures:
+            h, w = (t.image.shape[0], t.image.shape[1]) if t.image is not None else (0, 0)
+            out.append(struct.pack("<6i4d", t.type, t.even, t.odd, w, h, 0, t.rgb[0], t.rgb[1], t.rgb[2], t.scale))
+        for ob in self.objects:
+            out.append(struct.pack("<3Ii5d", ob.first_triangle, ob.n_triangles, ob.flags, ob.phase_material,
+                                   ob.rotate_y_degrees, *ob.offset, ob.density))
+        return b"".join(out)
+
+    def write_files(self, scene_path: str) -> None:
+        """The scene file and, beside it, the image files its image textures name (oracle/flat_scene.h)."""
+        from PIL import Image
+        with open(scene_path, "wb") as f:
+            f.write(self.to_bytes())
+        for i, t in enumerate(self.textures):
+            if t.type == TEX_IMAGE and t.image is not None:
+                Image.fromarray(np.ascontiguousarray(t.image, dtype=np.uint8), "RGB").save("%s.tex%d.png" % (scene_path, i))
+
+
+def _object_box(scene: FlatScene, a, b, mat: int) -> None:
+    add_box_triangles(scene, a, b, mat)
+
+
+def test_image(h: int = 12, w: int = 16) -> np.ndarray:
+    """Small RGB pattern with every value class the loader's byte conversion meets (0, 255, mid tones)."""
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 3), dtype=np.uint8)
+    img[..., 0] = (x * 255) // (w - 1)
+    img[..., 1] = (y * 255) // (h - 1)
+    img[..., 2] = ((x * 7 + y * 13) * 5) % 256
+    return img
+
+
+def _cornell_walls(s: FlatScene, light_rgb=(15.0, 15.0, 15.0)):
+    red = s.add_material(Material(LAMBERTIAN, (.65, .05, .05)))
+    white = s.add_material(Material(LAMBERTIAN, (.73, .73, .73)))
+    green = s.add_material(Material(LAMBERTIAN, (.12, .45, .15)))
+    light = s.add_material(Material(DIFFUSE_LIGHT, light_rgb))
+    add_quad_triangles(s, (555, 0, 0), (0, 0, 555), (0, 555, 0), green)
+    add_quad_triangles(s, (0, 0, 555), (0, 0, -555), (0, 555, 0), red)
+    add_quad_triangles(s, (0, 555, 0), (555, 0, 0), (0, 0, 555), white)
+    add_quad_triangles(s, (0, 0, 555), (555, 0, 0), (0, 0, -555), white)
+    add_quad_triangles(s, (555, 0, 555), (-555, 0, 0), (0, 555, 0), white)
+    return red, white, green, light
+
+
+def _cornell_camera(image_width, samples_per_pixel, max_depth, name):
+    return Camera(aspect_ratio=1.0, image_width=image_width, samples_per_pixel=samples_per_pixel, max_depth=max_depth,
+                  background=(0, 0, 0), vfov=40.0, lookfrom=(278, 278, -800), lookat=(278, 278, 0), vup=(0, 1, 0),
+                  defocus_angle=0.0, file_name=name)
+
+
+def cornell_instances(image_width: int = 32, samples_per_pixel: int = 16, max_depth: int = 8) -> CompositeScene:
+    """The Cornell box as a host of the reference would write it with instances: both boxes are meshes at the origin,
+    rotate_y(15) / rotate_y(-18) and translate put them in place (hittable.h:46-157); a third, metal box is only
+    translated and a fourth, glass one only rotated."""
+    s = CompositeScene()
+    red, white, green, light = _cornell_walls(s)
+    add_quad_triangles(s, (213, 554, 227), (130, 0, 0), (0, 0, 105), light)
+    metal = s.add_material(Material(METAL, (.8, .85, .88), fuzz=0.1))
+    glass = s.add_material(Material(DIELECTRIC, ior=1.5))
+    f = s.begin_object(); _object_box(s, (0, 0, 0), (165, 330, 165), white)
+    s.end_object(f, flags=OBJECT_ROTATE_Y | OBJECT_TRANSLATE, rotate_y_degrees=15.0, offset=(265, 0, 295))
+    f = s.begin_object(); _object_box(s, (0, 0, 0), (165, 165, 165), white)
+    s.end_object(f, flags=OBJECT_ROTATE_Y | OBJECT_TRANSLATE, rotate_y_degrees=-18.0, offset=(130, 0, 65))
+    f = s.begin_object(); _object_box(s, (0, 0, 0), (60, 60, 60), metal)
+    s.end_object(f, flags=OBJECT_TRANSLATE, offset=(420, 0.5, 60))
+    f = s.begin_object(); _object_box(s, (300, 340, 200), (380, 420, 280), glass)
+    s.end_object(f, flags=OBJECT_ROTATE_Y, rotate_y_degrees=8.0)
+    s.camera = _cornell_camera(image_width, samples_per_pixel, max_depth, "cornell_instances.png")
+    return s
+
+
+def cornell_textures(image_width: int = 32, samples_per_pixel: int = 16, max_depth: int = 8) -> CompositeScene:
+    """Cornell box whose surfaces carry every texture class (texture.h:28-87): a checker floor whose odd squares are
+    themselves marble noise, a noise back wall, an image on the left wall, a checkered emitter, and a box instance
+    with a checker of two solid colours."""
+    s = CompositeScene()
+    c_white = s.add_texture(Texture(TEX_SOLID, rgb=(.73, .73, .73)))
+    c_dark = s.add_texture(Texture(TEX_SOLID, rgb=(.2, .3, .1)))
+    marble = s.add_texture(Texture(TEX_NOISE, scale=0.05))
+    floor_t = s.add_texture(Texture(TEX_CHECKER, scale=80.0, even=c_white, odd=marble))
+    wall_t = s.add_texture(Texture(TEX_NOISE, scale=0.02))
+    image_t = s.add_texture(Texture(TEX_IMAGE, image=test_image()))
+    e_hi = s.add_texture(Texture(TEX_SOLID, rgb=(18.0, 17.0, 15.0)))
+    e_lo = s.add_texture(Texture(TEX_SOLID, rgb=(6.0, 8.0, 12.0)))
+    emit_t = s.add_texture(Texture(TEX_CHECKER, scale=30.0, even=e_hi, odd=e_lo))
+    box_t = s.add_texture(Texture(TEX_CHECKER, scale=40.0, even=c_dark, odd=c_white))
+    red = s.add_material(Material(LAMBERTIAN, (.65, .05, .05)))
+    white = s.add_material(Material(LAMBERTIAN, (.73, .73, .73)))
+    floor_m = s.add_material(Material(LAMBERTIAN, texture=floor_t))
+    wall_m = s.add_material(Material(LAMBERTIAN, texture=wall_t))
+    image_m = s.add_material(Material(LAMBERTIAN, texture=image_t))
+    light = s.add_material(Material(DIFFUSE_LIGHT, texture=emit_t))
+    box_m = s.add_material(Material(LAMBERTIAN, texture=box_t))
+    add_quad_triangles(s, (555, 0, 0), (0, 0, 555), (0, 555, 0), image_m)
+    add_quad_triangles(s, (0, 0, 555), (0, 0, -555), (0, 555, 0), red)
+    add_quad_triangles(s, (0, 555, 0), (555, 0, 0), (0, 0, 555), white)
+    add_quad_triangles(s, (0, 0, 555), (555, 0, 0), (0, 0, -555), floor_m)
+    add_quad_triangles(s, (555, 0, 555), (-555, 0, 0), (0, 555, 0), wall_m)
+    add_quad_triangles(s, (183, 554, 197), (190, 0, 0), (0, 0, 165), light)
+    f = s.begin_object(); _object_box(s, (0, 0, 0), (165, 330, 165), box_m)
+    s.end_object(f, flags=OBJECT_ROTATE_Y | OBJECT_TRANSLATE, rotate_y_degrees=15.0, offset=(265, 0, 295))
+    s.camera = _cornell_camera(image_width, samples_per_pixel, max_depth, "cornell_textures.png")
+    return s
+
+
+def cornell_smoke(image_width: int = 32, samples_per_pixel: int = 16, max_depth: int = 8) -> CompositeScene:
+    """Cornell box with the two boxes as volumes of constant density (constant_medium.h): white smoke in the rotated
+    and translated tall box, dark smoke with a marble-noise albedo in the short one, a thin haze box that is not
+    transformed at all, and a solid mirror box in front of them."""
+    s = CompositeScene()
+    red, white, green, light = _cornell_walls(s, (7.0, 7.0, 7.0))
+    add_quad_triangles(s, (113, 554, 127), (330, 0, 0), (0, 0, 305), light)
+    noise_t = s.add_texture(Texture(TEX_NOISE, scale=0.03))
+    smoke_w = s.add_material(Material(ISOTROPIC, (1.0, 1.0, 1.0)))
+    smoke_d = s.add_material(Material(ISOTROPIC, texture=noise_t))
+    haze = s.add_material(Material(ISOTROPIC, (.6, .7, .9)))
+    mirror = s.add_material(Material(METAL, (.9, .9, .9), fuzz=0.0))
+    f = s.begin_object(); _object_box(s, (0, 0, 0), (165, 330, 165), white)
+    s.end_object(f, flags=OBJECT_ROTATE_Y | OBJECT_TRANSLATE | OBJECT_MEDIUM, rotate_y_degrees=15.0, offset=(265, 0, 295),
+                 density=0.01, phase_material=smoke_w)
+    f = s.begin_object(); _object_box(s, (0, 0, 0), (165, 165, 165), white)
+    s.end_object(f, flags=OBJECT_ROTATE_Y | OBJECT_TRANSLATE | OBJECT_MEDIUM, rotate_y_degrees=-18.0, offset=(130, 0, 65),
+                 density=0.02, phase_material=smoke_d)
+    f = s.begin_object(); _object_box(s, (20, 20, 20), (535, 200, 535), white)
+    s.end_object(f, flags=OBJECT_MEDIUM, density=0.0008, phase_material=haze)
+    f = s.begin_object(); _object_box(s, (0, 0, 0), (70, 70, 70), mirror)
+    s.end_object(f, flags=OBJECT_ROTATE_Y | OBJECT_TRANSLATE, rotate_y_degrees=30.0, offset=(380, 0, 90))
+    s.camera = _cornell_camera(image_width, samples_per_pixel, max_depth, "cornell_smoke.png")
+    return s
 
 # ------------------------------------------------------------------------------- scenes
 def cornell_box(image_width: int = 512, samples_per_pixel: int = 256, max_depth: int = 10,

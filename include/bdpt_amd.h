@@ -33,17 +33,20 @@ extern "C" {
 typedef struct bdpt_context bdpt_context;
 typedef struct bdpt_scene bdpt_scene;
 
-/* Material kinds (src/materials/material.h:42-147). */
+/* Material kinds (src/materials/material.h:42-172). */
 enum {
     BDPT_LAMBERTIAN = 0,     /* rgb = albedo                      material.h:42-67   */
     BDPT_METAL = 1,          /* rgb = albedo, fuzz (clamped to 1) material.h:69-90   */
     BDPT_DIELECTRIC = 2,     /* ior                               material.h:92-131  */
-    BDPT_DIFFUSE_LIGHT = 3   /* rgb = emitted radiance            material.h:133-147 */
+    BDPT_DIFFUSE_LIGHT = 3,  /* rgb = emitted radiance            material.h:133-147 */
+    BDPT_ISOTROPIC = 4       /* rgb = albedo; the phase function of a constant_medium, material.h:149-172
+                                (bdpt_scene_create_composite only) */
 };
 
 typedef struct bdpt_material {
     int32_t type;
-    int32_t reserved;
+    int32_t reserved;        /* bdpt_scene_create_composite: 0 = the solid colour `rgb`, k > 0 = texture k - 1
+                                (lambertian, diffuse_light and isotropic take a texture, material.h:45,135,152) */
     double rgb[3];
     double fuzz;
     double ior;
@@ -187,6 +190,68 @@ int bdpt_scene_dfs_leaves(const bdpt_scene* scene, uint32_t* out, uint32_t capac
 /* Boxes of the bvh_node objects in pre-order: xmin xmax ymin ymax zmin zmax (6 doubles per node). */
 int bdpt_scene_node_boxes(const bdpt_scene* scene, double* out, uint32_t capacity_nodes);
 
+
+/* ---- composite scenes: instances, textures, participating media ----
+ * The parts of the reference's object model that no scene file reaches but a C++ host can build:
+ * translate / rotate_y (src/objects/hittable.h:46-157), checker / noise / image textures
+ * (src/materials/textures/texture.h:28-87, perlin.h) and constant_medium with its isotropic phase function
+ * (src/materials/volumes/constant_medium.h, src/materials/material.h:149-172). */
+enum {
+    BDPT_TEX_SOLID = 0,      /* rgb                                                  texture.h:14-26 */
+    BDPT_TEX_CHECKER = 1,    /* scale, even, odd (texture indices)                   texture.h:28-50 */
+    BDPT_TEX_NOISE = 2,      /* scale, data = bdpt_perlin_tables                     texture.h:76-87 */
+    BDPT_TEX_IMAGE = 3       /* width, height, data = width*height*3 bytes           texture.h:52-74 */
+};
+/* What a `perlin` object holds after its constructor ran (perlin.h:53-57). */
+typedef struct bdpt_perlin_tables {
+    double randvec[256][3];
+    int32_t perm_x[256], perm_y[256], perm_z[256];
+} bdpt_perlin_tables;
+typedef struct bdpt_texture {
+    int32_t type;
+    int32_t even, odd;       /* checker: the two sub-textures */
+    int32_t width, height;   /* image: size in pixels; height <= 0 = "no image data" (solid cyan, texture.h:58) */
+    int32_t reserved;
+    double rgb[3];           /* solid */
+    double scale;            /* checker: the constructor's `scale` (1/scale is formed as in texture.h:31); noise: `scale` */
+    const void* data;        /* noise: const bdpt_perlin_tables*; image: 8-bit RGB rows, top row first, 3 bytes per pixel
+                                (rtw_image::bdata, src/image/rtw_stb_image.h:98-112); read during the call only */
+} bdpt_texture;
+
+#define BDPT_OBJECT_ROTATE_Y 1   /* rotate_y(object, rotate_y_degrees), hittable.h:76-157 */
+#define BDPT_OBJECT_TRANSLATE 2  /* translate(object, offset), hittable.h:46-74; applied after the rotation, i.e. the
+                                    host's translate(rotate_y(mesh, angle), offset) */
+#define BDPT_OBJECT_MEDIUM 4     /* constant_medium(boundary = the (transformed) mesh, density, phase), constant_medium.h */
+/* One entry of the world's hittable_list that is not a bare triangle: a mesh of its own
+ * (`bvh_node(hittable_list of its triangles)`, given in the mesh's own coordinates), optionally rotated about the
+ * y axis, translated, and turned into a volume of constant density. */
+typedef struct bdpt_object {
+    uint32_t first_triangle;     /* the mesh: triangles [first_triangle, first_triangle + n_triangles) */
+    uint32_t n_triangles;
+    uint32_t flags;              /* BDPT_OBJECT_* */
+    int32_t phase_material;      /* BDPT_OBJECT_MEDIUM: index of a BDPT_ISOTROPIC material */
+    double rotate_y_degrees;
+    double offset[3];
+    double density;              /* BDPT_OBJECT_MEDIUM: neg_inv_density = -1/density, constant_medium.h:11 */
+} bdpt_object;
+
+/* bdpt_scene_create for a world that also holds such objects.  The world's hittable_list is: the triangles that
+ * belong to no object, each as its own entry, and the objects, each entry at the place of its first triangle -
+ * i.e. the order of the triangle array; `bvh_node(list)` is built over it as in src/main.cpp:66.  Object ranges must
+ * not overlap and must be in ascending order.  Light triangles (the `lights` collection) must be triangles that
+ * belong to no object; n_lights == 0 selects all of those.
+ * The resulting scene renders through every bdpt_render* entry point except bdpt_render_device_static, on the
+ * single-kernel path (one thread per sample, the reference's own traversal order: constant_medium::hit draws its
+ * random number INSIDE the BVH walk, constant_medium.h:40, so the visiting order is part of the result) and answers
+ * bdpt_trace_closest* / bdpt_visible; query i draws from stream (seed 0, pixel i, sample 0).  A hit inside a
+ * medium reports -(2 + object index) as its triangle id and u = v = 0 (the reference leaves them unset).
+ * BDPT_RENDER_UNIDIRECTIONAL is not available for composite scenes.  An isotropic material with an image texture
+ * is refused: the reference reads unset u, v there (constant_medium.h:45-50, material.h:155). */
+int bdpt_scene_create_composite(bdpt_context* ctx, const double* tri_vertices, const int32_t* tri_material,
+                                uint32_t n_triangles, const bdpt_material* materials, uint32_t n_materials,
+                                const bdpt_texture* textures, uint32_t n_textures, const bdpt_object* objects,
+                                uint32_t n_objects, const uint32_t* light_triangles, uint32_t n_lights, bdpt_scene** out);
+
 /* bvh_node::hit(r, interval(tmin, tmax), rec), src/acceleration/bvh.h:50-59, for n rays.
  *   rays : n * 8 doubles (origin[3] direction[3] tmin tmax)
  *   hits : n * 11 doubles (triangle id or -1, t, u, v, front_face, p[3], normal[3]) = hit_record
@@ -282,14 +347,16 @@ int bdpt_write_png(const char* file_name, const uint8_t* rgb, int32_t width, int
 int bdpt_debug_yaml_to_json(const char* text, char* out, uint64_t capacity);
 
 /* Test hooks for the device-side building blocks the path is made of. */
-/* std::cos / std::sin of src/core/vec3.h:154-155 as evaluated on the GPU (0 <= x <= 8). */
+/* std::cos / std::sin of src/core/vec3.h:154-155, src/materials/textures/texture.h:81 and src/objects/hittable.h:80-81
+ * as evaluated on the GPU (|x| <= 2^30). */
 int bdpt_device_sincos(bdpt_context* ctx, const double* x, uint64_t n, double* sin_out, double* cos_out);
 /* first n values random_double() returns inside sample `sample` of pixel `pixel` (src/main.h:28-32). */
 int bdpt_device_random_doubles(bdpt_context* ctx, uint64_t seed, uint64_t pixel, uint64_t sample, uint64_t n,
                                double* out);
 
 /* element-wise IEEE checks on the GPU: op 0 a/b, 1 sqrt(a), 2 fma(a,b,a), 3 a*b+a (two roundings),
- * 4 fmin, 5 fmax, 6 a^5 as the device evaluates pow(.,5) of src/materials/material.h:129, 7 1/a */
+ * 4 fmin, 5 fmax, 6 a^5 as the device evaluates pow(.,5) of src/materials/material.h:129, 7 1/a,
+ * 8 log(a) as the device evaluates the std::log of src/materials/volumes/constant_medium.h:40 */
 int bdpt_device_arith(bdpt_context* ctx, int op, const double* a, const double* b, uint64_t n, double* out);
 
 #ifdef __cplusplus

@@ -937,6 +937,9 @@ void oracle_sincos_array(const double* x, uint64_t n, double* s, double* c) {
 void oracle_pow5_array(const double* x, uint64_t n, double* out) {
     for (uint64_t i = 0; i < n; i++) out[i] = oracle_pow5(x[i]);
 }
+void oracle_log_array(const double* x, uint64_t n, double* out) {
+    for (uint64_t i = 0; i < n; i++) out[i] = oracle_log(x[i]);
+}
 void oracle_rng_array(uint64_t seed, uint64_t pixel, uint64_t sample, uint64_t n, double* out) {
     orng_stream st;
     st.key = orng_stream_key(seed, pixel, sample);

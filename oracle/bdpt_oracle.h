@@ -82,6 +82,7 @@ void oracle_colors_to_rgb8(const double* fb, int32_t W, int32_t H, int32_t sampl
 /* the deterministic math shared with the HIP kernels */
 void oracle_sincos_array(const double* x, uint64_t n, double* s, double* c);
 void oracle_pow5_array(const double* x, uint64_t n, double* out);
+void oracle_log_array(const double* x, uint64_t n, double* out);
 /* first n doubles of stream (seed, pixel, sample) */
 void oracle_rng_array(uint64_t seed, uint64_t pixel, uint64_t sample, uint64_t n, double* out);
 void oracle_mt_array(uint64_t n, double* out);

@@ -97,15 +97,17 @@ static const double ODD_C[15][2] = {
     { 0x1.0a18a2635085dp-98,  0x1.b9e2e28e1aa54p-153 },
 };
 
-/* sin and cos of x for 0 <= x <= 8 (the reference only ever passes phi = 2*pi*r1, r1 in [0,1)).
- * Outside that range the quadrant reduction below is not valid. */
+/* sin and cos of x for |x| <= 2^30.  The hot path passes phi = 2*pi*r1, r1 in [0,1) (src/core/vec3.h:153-155);
+ * noise_texture::value passes scale*z + 10*turbulence (src/materials/textures/texture.h:81) and rotate_y an angle in
+ * radians (src/objects/hittable.h:79-81).  pi/2 is carried to 2^-164, so the reduced argument keeps ~100 good bits
+ * for every such x; beyond 2^30 the quadrant no longer fits an int and the caller must use another routine. */
 static inline void oracle_sincos(double x, double* s_out, double* c_out) {
-    /* quadrant: k = nearest integer to x * 2/pi  (0..5) */
+    /* quadrant: k = nearest integer to x * 2/pi */
     double kd = rint(x * 0x1.45f306dc9c883p-1);
     int k = (int)kd;
     /* r = x - k*pi/2 as a double-double; pi/2 = P1 + P2 + P3 (+ 2^-164) */
     const double P1 = 0x1.921fb54442d18p+0, P2 = 0x1.1a62633145c07p-54, P3 = -0x1.f1976b7ed8fbcp-110;
-    double r0 = fma(-kd, P1, x);               /* exact: both terms are multiples of 2^-53, |r0| < 1 */
+    double r0 = fma(-kd, P1, x);               /* exact: both terms are multiples of 2^-52, |r0| < 1 */
     odd_t p2 = odd_two_prod(kd, P2);
     odd_t r = odd_two_sum(r0, -p2.hi);
     r.lo = r.lo - p2.lo;
@@ -151,6 +153,78 @@ static inline double oracle_pow5(double x) {
     odd_t x4 = odd_mul(x2, x2);
     odd_t x5 = odd_mul_d(x4, x);
     return x5.hi;
+}
+
+/* 1/(2k+1), k = 0..21, as double-double */
+static const double ODD_ODDREC[22][2] = {
+    { 0x1.0000000000000p+0, 0x0.0p+0 },
+    { 0x1.5555555555555p-2, 0x1.5555555555555p-56 },
+    { 0x1.999999999999ap-3, -0x1.999999999999ap-57 },
+    { 0x1.2492492492492p-3, 0x1.2492492492492p-57 },
+    { 0x1.c71c71c71c71cp-4, 0x1.c71c71c71c71cp-58 },
+    { 0x1.745d1745d1746p-4, -0x1.745d1745d1746p-59 },
+    { 0x1.3b13b13b13b14p-4, -0x1.3b13b13b13b14p-58 },
+    { 0x1.1111111111111p-4, 0x1.1111111111111p-60 },
+    { 0x1.e1e1e1e1e1e1ep-5, 0x1.e1e1e1e1e1e1ep-61 },
+    { 0x1.af286bca1af28p-5, 0x1.af286bca1af28p-59 },
+    { 0x1.8618618618618p-5, 0x1.8618618618618p-59 },
+    { 0x1.642c8590b2164p-5, 0x1.642c8590b2164p-60 },
+    { 0x1.47ae147ae147bp-5, -0x1.eb851eb851eb8p-61 },
+    { 0x1.2f684bda12f68p-5, 0x1.2f684bda12f68p-59 },
+    { 0x1.1a7b9611a7b96p-5, 0x1.1a7b9611a7b96p-61 },
+    { 0x1.0842108421084p-5, 0x1.0842108421084p-60 },
+    { 0x1.f07c1f07c1f08p-6, -0x1.f07c1f07c1f08p-61 },
+    { 0x1.d41d41d41d41dp-6, 0x1.0750750750750p-60 },
+    { 0x1.bacf914c1bad0p-6, -0x1.bacf914c1bad0p-60 },
+    { 0x1.a41a41a41a41ap-6, 0x1.0690690690690p-60 },
+    { 0x1.8f9c18f9c18fap-6, -0x1.f3831f3831f38p-61 },
+    { 0x1.7d05f417d05f4p-6, 0x1.7d05f417d05f4p-62 },
+};
+
+/* a / b in double-double (three quotient digits) */
+static inline odd_t odd_div(odd_t a, odd_t b) {
+    double q1 = a.hi / b.hi;
+    odd_t nb = odd_mul_d(b, -q1);
+    odd_t r = odd_add(a, nb);
+    double q2 = r.hi / b.hi;
+    nb = odd_mul_d(b, -q2);
+    r = odd_add(r, nb);
+    double q3 = r.hi / b.hi;
+    odd_t q = odd_fast_two_sum(q1, q2);
+    odd_t t; t.hi = q3; t.lo = 0.0;
+    return odd_add(q, t);
+}
+
+/* Natural logarithm of a positive finite x (constant_medium::hit takes std::log(random_double()),
+ * src/materials/volumes/constant_medium.h:40).  x = m * 2^e with sqrt(1/2) <= m < sqrt(2);
+ * log m = 2 atanh(s), s = (m - 1)/(m + 1), |s| < 0.1716, 22 terms of the series in double-double;
+ * e * ln 2 from a three-part ln 2 whose first part has 42 bits (e * L1 is exact). */
+static inline double oracle_log(double x) {
+    if (x != x || x < 0.0) return NAN;
+    if (x == 0.0) return -INFINITY;
+    if (x == INFINITY) return x;
+    int e;
+    double m = frexp(x, &e);                   /* 0.5 <= m < 1 */
+    if (m < 0x1.6a09e667f3bcdp-1) { m = m * 2.0; e = e - 1; }
+    const double f = m - 1.0;                  /* exact */
+    odd_t num; num.hi = f; num.lo = 0.0;
+    odd_t den = odd_two_sum(2.0, f);
+    odd_t s = odd_div(num, den);
+    odd_t z = odd_mul(s, s);
+    odd_t acc; acc.hi = ODD_ODDREC[21][0]; acc.lo = ODD_ODDREC[21][1];
+    for (int k = 20; k >= 0; k--) {
+        odd_t c; c.hi = ODD_ODDREC[k][0]; c.lo = ODD_ODDREC[k][1];
+        acc = odd_add(c, odd_mul(acc, z));
+    }
+    odd_t lm = odd_mul(acc, s);
+    lm.hi = lm.hi * 2.0; lm.lo = lm.lo * 2.0;  /* log m */
+    const double L1 = 0x1.62e42fefa3800p-1, L2 = 0x1.ef35793c76730p-45, L3 = 0x1.f97b57a079a19p-103;
+    const double ed = (double)e;
+    odd_t t1; t1.hi = ed * L1; t1.lo = 0.0;    /* exact */
+    odd_t t2 = odd_two_prod(ed, L2);
+    t2.lo = t2.lo + ed * L3;
+    odd_t r = odd_add(odd_add(t1, t2), lm);
+    return r.hi;
 }
 
 #endif

@@ -55,15 +55,54 @@
 #include "material.h"
 #include "triangle.h"
 #include "texture.h"
+#include "constant_medium.h"
 #undef private
+
+// textures of a composite scene, in file order (children of a checker come first)
+static std::vector<std::shared_ptr<texture>> g_textures;
+
+#ifndef HARNESS_NO_SHIM
+// A noise_texture fills its perlin tables from the global generator when it is constructed (perlin.h:6-14): every
+// noise texture is built on a stream of its own so that the tables do not depend on what was drawn before.
+static void seed_for_noise_texture(uint32_t index) {
+    harness_rng().engine = 0;
+    harness_rng().stream.key = orng_stream_key(0x7065726c696eULL, index, 0);
+    harness_rng().stream.counter = 0;
+}
+#endif
+
+static void make_textures(const fs_scene& fs, const char* scene_path) {
+    g_textures.clear();
+    for (uint32_t i = 0; i < fs.n_textures; i++) {
+        const fs_texture& t = fs.textures[i];
+        switch (t.type) {
+            case 0: g_textures.push_back(std::make_shared<solid_color>(color(t.rgb[0], t.rgb[1], t.rgb[2]))); break;
+            case 1: g_textures.push_back(std::make_shared<checker_texture>(t.scale, g_textures.at(t.even), g_textures.at(t.odd))); break;
+            case 2:
+#ifndef HARNESS_NO_SHIM
+                seed_for_noise_texture(i);
+#endif
+                g_textures.push_back(std::make_shared<noise_texture>(t.scale));
+                break;
+            case 3: {
+                const std::string file = std::string(scene_path) + ".tex" + std::to_string(i) + ".png";
+                g_textures.push_back(std::make_shared<image_texture>(file.c_str()));
+                break;
+            }
+            default: fprintf(stderr, "bad texture type %d\n", t.type); exit(2);
+        }
+    }
+}
 
 static std::shared_ptr<material> make_material(const fs_material& m) {
     color c(m.rgb[0], m.rgb[1], m.rgb[2]);
+    std::shared_ptr<texture> tex = (m.pad > 0) ? g_textures.at(m.pad - 1) : nullptr;
     switch (m.type) {
-        case 0: return std::make_shared<lambertian>(c);
+        case 0: return tex ? std::make_shared<lambertian>(tex) : std::make_shared<lambertian>(c);
         case 1: return std::make_shared<metal>(c, m.fuzz);
         case 2: return std::make_shared<dielectric>(m.ior);
-        case 3: return std::make_shared<diffuse_light>(c);
+        case 3: return tex ? std::make_shared<diffuse_light>(tex) : std::make_shared<diffuse_light>(c);
+        case 4: return tex ? std::make_shared<isotropic>(tex) : std::make_shared<isotropic>(c);
     }
     fprintf(stderr, "bad material type %d\n", m.type);
     exit(2);
@@ -75,6 +114,9 @@ struct built_scene {
     std::vector<std::shared_ptr<material>> mats;
     std::shared_ptr<bvh_node> bvh;
     std::vector<std::shared_ptr<hittable>> leaf_ptrs;   // world triangle i -> the heap copy the BVH holds
+    std::vector<std::shared_ptr<hittable>> objects;     // composite scenes: object k as it stands in the world's list
+    std::vector<const material*> phase;                 // composite scenes: phase function of object k (or null)
+    std::vector<std::shared_ptr<material>> tri_mats;    // material object of world triangle i
     camera cam;
 };
 
@@ -83,23 +125,76 @@ static point3 P(const double* v) { return point3(v[0], v[1], v[2]); }
 // unique_materials: give every triangle its own material object so that a hit_record's
 // `mat` pointer identifies the triangle that was hit (used only by the `hits` operation;
 // material values do not take part in intersection).
-static void build(const fs_scene& fs, built_scene& b, bool unique_materials) {
+static void build(const fs_scene& fs, built_scene& b, bool unique_materials, const char* scene_path) {
+    make_textures(fs, scene_path);
     for (uint32_t i = 0; i < fs.n_materials; i++) b.mats.push_back(make_material(fs.materials[i]));
-    std::vector<std::shared_ptr<material>> tri_mats;
+    std::vector<std::shared_ptr<material>>& tri_mats = b.tri_mats;
     for (uint32_t i = 0; i < fs.n_triangles; i++) {
         const fs_triangle& t = fs.triangles[i];
         std::shared_ptr<material> m = unique_materials ? make_material(fs.materials[t.material]) : b.mats[t.material];
         tri_mats.push_back(m);
         b.world.add(triangle(P(t.v0), P(t.v1), P(t.v2), m));
     }
-    for (uint32_t i = 0; i < fs.n_lights; i++) {
-        const fs_triangle& t = fs.triangles[fs.lights[i]];
-        b.lights.add(triangle(P(t.v0), P(t.v1), P(t.v2), tri_mats[fs.lights[i]]));
+    if (!fs.composite) {
+        for (uint32_t i = 0; i < fs.n_lights; i++) {
+            const fs_triangle& t = fs.triangles[fs.lights[i]];
+            b.lights.add(triangle(P(t.v0), P(t.v1), P(t.v2), tri_mats[fs.lights[i]]));
+        }
+        // src/main.cpp:66 : bvh_node(world.to_hittable_list())
+        hittable_list list = b.world.to_hittable_list();
+        b.leaf_ptrs = list.objects;
+        if (fs.n_triangles > 0) b.bvh = std::make_shared<bvh_node>(list);
+    } else {
+        // The world a C++ host of the reference would assemble: bare triangles and, per object, the mesh as a
+        // bvh_node of its own wrapped in rotate_y / translate / constant_medium (hittable.h:46-157,
+        // constant_medium.h), all in one hittable_list handed to bvh_node as in src/main.cpp:66.
+        std::vector<int> owner(fs.n_triangles, -1);
+        for (uint32_t k = 0; k < fs.n_objects; k++)
+            for (uint32_t i = 0; i < fs.objects[k].n_triangles; i++) owner[fs.objects[k].first_triangle + i] = (int)k;
+        hittable_list list;
+        b.leaf_ptrs.assign(fs.n_triangles, nullptr);
+        b.objects.assign(fs.n_objects, nullptr);
+        b.phase.assign(fs.n_objects, nullptr);
+        std::vector<uint32_t> loose;
+        for (uint32_t i = 0; i < fs.n_triangles;) {
+            if (owner[i] < 0) {
+                auto tp = make_shared<triangle>(b.world.tris[i]);
+                b.leaf_ptrs[i] = tp;
+                list.add(tp);
+                loose.push_back(i);
+                i++;
+                continue;
+            }
+            const fs_object& ob = fs.objects[owner[i]];
+            hittable_list mesh;
+            for (uint32_t q = 0; q < ob.n_triangles; q++) {
+                auto tp = make_shared<triangle>(b.world.tris[ob.first_triangle + q]);
+                b.leaf_ptrs[ob.first_triangle + q] = tp;
+                mesh.add(tp);
+            }
+            shared_ptr<hittable> h = make_shared<bvh_node>(mesh);
+            if (ob.flags & 1u) h = make_shared<rotate_y>(h, ob.rotate_y_degrees);
+            if (ob.flags & 2u) h = make_shared<translate>(h, vec3(ob.offset[0], ob.offset[1], ob.offset[2]));
+            if (ob.flags & 4u) {
+                const fs_material& pm = fs.materials[ob.phase_material];
+                shared_ptr<constant_medium> cm = (pm.pad > 0)
+                    ? make_shared<constant_medium>(h, ob.density, g_textures.at(pm.pad - 1))
+                    : make_shared<constant_medium>(h, ob.density, color(pm.rgb[0], pm.rgb[1], pm.rgb[2]));
+                b.phase[owner[i]] = cm->phase_function.get();
+                h = cm;
+            }
+            b.objects[owner[i]] = h;
+            list.add(h);
+            i += ob.n_triangles;
+        }
+        // the light collection: the listed triangles, or every triangle of the world's list
+        if (fs.n_lights > 0) { loose.clear(); for (uint32_t i = 0; i < fs.n_lights; i++) loose.push_back(fs.lights[i]); }
+        for (uint32_t id : loose) {
+            const fs_triangle& t = fs.triangles[id];
+            b.lights.add(triangle(P(t.v0), P(t.v1), P(t.v2), tri_mats[id]));
+        }
+        b.bvh = std::make_shared<bvh_node>(list);
     }
-    // src/main.cpp:66 : bvh_node(world.to_hittable_list())
-    hittable_list list = b.world.to_hittable_list();
-    b.leaf_ptrs = list.objects;
-    if (fs.n_triangles > 0) b.bvh = std::make_shared<bvh_node>(list);
 
     const fs_camera& c = fs.camera;
     b.cam.aspect_ratio = c.aspect_ratio;
@@ -146,16 +241,18 @@ static void push_stats(std::vector<double>& out) {
 
 // DFS (left then right) over the reference tree: leaf triangle ids in visiting order and
 // every bvh_node's box in pre-order.
+static std::map<const hittable*, double> g_object_ids;    // composite scenes: object k -> -(k + 2)
 static void walk(const hittable* h, const std::map<const hittable*, uint32_t>& ids,
                  std::vector<double>& leaves, std::vector<double>& boxes) {
-    if (const bvh_node* n = dynamic_cast<const bvh_node*>(h)) {
+    const bvh_node* n = g_object_ids.count(h) ? nullptr : dynamic_cast<const bvh_node*>(h);   // an object is a leaf of the world's tree
+    if (n) {
         boxes.push_back(n->bbox.x.min); boxes.push_back(n->bbox.x.max);
         boxes.push_back(n->bbox.y.min); boxes.push_back(n->bbox.y.max);
         boxes.push_back(n->bbox.z.min); boxes.push_back(n->bbox.z.max);
         walk(n->left.get(), ids, leaves, boxes);
         walk(n->right.get(), ids, leaves, boxes);
     } else {
-        leaves.push_back((double)ids.at(h));
+        leaves.push_back(ids.count(h) ? (double)ids.at(h) : g_object_ids.at(h));
     }
 }
 
@@ -189,11 +286,38 @@ int main(int argc, char** argv) {
     if (fs_load(argv[1], &fs) != 0) { fprintf(stderr, "bad scene file\n"); return 2; }
 
     built_scene b;
-    build(fs, b, op == "hits");
+    build(fs, b, op == "hits", argv[1]);
     camera& cam = b.cam;
     cam.initialize();
     // src/main.cpp:67
     const triangle_collection& lights = b.lights.empty() ? b.world : b.lights;
+    for (uint32_t k = 0; k < b.objects.size(); k++) g_object_ids[b.objects[k].get()] = -(double)(k + 2);
+
+    if (op == "perlin") {   // argv[3] out.bin: per noise texture 768 doubles (randvec) then 768 doubles (perm_x, perm_y, perm_z)
+        std::vector<double> o;
+        for (uint32_t i = 0; i < fs.n_textures; i++) {
+            if (fs.textures[i].type != 2) continue;
+            const noise_texture* nt = static_cast<const noise_texture*>(g_textures[i].get());
+            for (int k = 0; k < 256; k++) for (int a = 0; a < 3; a++) o.push_back(nt->noise.randvec[k][a]);
+            for (int k = 0; k < 256; k++) o.push_back(nt->noise.perm_x[k]);
+            for (int k = 0; k < 256; k++) o.push_back(nt->noise.perm_y[k]);
+            for (int k = 0; k < 256; k++) o.push_back(nt->noise.perm_z[k]);
+        }
+        write_file(argv[3], o.data(), o.size() * 8);
+        return 0;
+    }
+    if (op == "image_bytes") {   // argv[3] out.bin: per image texture width, height (2 doubles) then its bytes as doubles
+        std::vector<double> o;
+        for (uint32_t i = 0; i < fs.n_textures; i++) {
+            if (fs.textures[i].type != 3) continue;
+            const image_texture* it = static_cast<const image_texture*>(g_textures[i].get());
+            const int w = it->image.width(), h = it->image.height();
+            o.push_back(w); o.push_back(h);
+            for (int k = 0; k < w * h * 3; k++) o.push_back(it->image.bdata[k]);
+        }
+        write_file(argv[3], o.data(), o.size() * 8);
+        return 0;
+    }
 
     if (op == "camera") {
         std::vector<double> o;
@@ -235,8 +359,9 @@ int main(int argc, char** argv) {
     }
 
     if (op == "hits") {   // argv[3] rays.bin (o[3] d[3] tmin tmax)*  argv[4] out.bin
-        std::map<const material*, uint32_t> by_mat;
-        for (uint32_t i = 0; i < b.world.tris.size(); i++) by_mat[b.world.tris[i].mat.get()] = i;
+        std::map<const material*, double> by_mat;
+        for (uint32_t i = 0; i < b.world.tris.size(); i++) by_mat[b.world.tris[i].mat.get()] = (double)i;
+        for (uint32_t k = 0; k < b.phase.size(); k++) if (b.phase[k]) by_mat[b.phase[k]] = -(double)(k + 2);
         std::vector<double> rays = read_doubles(argv[3]);
         size_t n = rays.size() / 8;
         std::vector<double> out;
@@ -246,12 +371,18 @@ int main(int argc, char** argv) {
             const double* r = &rays[i * 8];
             ray rr(point3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]), 0.0);
             hit_record rec;
+            rec.u = 0; rec.v = 0;                        // (a medium leaves them unset, constant_medium.h:45-50)
+#ifndef HARNESS_NO_SHIM
+            harness_rng().engine = 0;                    // query i owns stream (seed 0, pixel i, sample 0): media draw
+            harness_rng().stream.key = orng_stream_key(0, i, 0);
+            harness_rng().stream.counter = 0;
+#endif
             bool h = b.bvh->hit(rr, interval(r[6], r[7]), rec);
             if (!h) {
                 out.push_back(-1.0);
                 for (int k = 0; k < 10; k++) out.push_back(0.0);
             } else {
-                out.push_back((double)by_mat.at(rec.mat.get()));
+                out.push_back(by_mat.at(rec.mat.get()));
                 out.push_back(rec.t); out.push_back(rec.u); out.push_back(rec.v);
                 out.push_back(rec.front_face ? 1.0 : 0.0);
                 for (int k = 0; k < 3; k++) out.push_back(rec.p[k]);
@@ -271,6 +402,11 @@ int main(int argc, char** argv) {
         std::vector<double> out;
         for (size_t i = 0; i < n; i++) {
             const double* p = &pairs[i * 6];
+#ifndef HARNESS_NO_SHIM
+            harness_rng().engine = 0;
+            harness_rng().stream.key = orng_stream_key(0, i, 0);
+            harness_rng().stream.counter = 0;
+#endif
             out.push_back(cam.visible(point3(p[0], p[1], p[2]), point3(p[3], p[4], p[5]), *b.bvh) ? 1.0 : 0.0);
         }
         write_file(argv[4], out.data(), out.size() * 8);

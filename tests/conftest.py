@@ -56,3 +56,23 @@ GOLDEN_CASES = {
 def sha256_of(a):
     import hashlib
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+# fixtures of composite scenes (instances, textures, media): name -> scene builder
+COMPOSITE_CASES = {
+    "cx_instances": lambda s: s.cornell_instances(32, 16, 8),
+    "cx_textures": lambda s: s.cornell_textures(32, 16, 8),
+    "cx_smoke": lambda s: s.cornell_smoke(32, 16, 8),
+}
+
+
+def composite_scene(scenes, name):
+    """The scene of a composite fixture with what the reference's texture objects held (perlin tables, image bytes)
+    attached, i.e. the input a host hands to bdpt_scene_create_composite."""
+    import hashlib
+    flat = COMPOSITE_CASES[name](scenes)
+    g = load_golden(name)
+    assert hashlib.sha256(flat.to_bytes()).digest() == bytes(g["scene_sha256"]), "scene builder drifted from the fixture"
+    flat.perlin_tables = [t for t in g["perlin_tables"]]
+    flat.image_bytes = [g["image_bytes_%d" % k] for k in range(int(g["n_images"][0]))]
+    return flat, g

@@ -132,6 +132,7 @@ class Oracle:
         lib.oracle_colors_to_rgb8.argtypes = [_d, C.c_int32, C.c_int32, C.c_int32, _u8]
         lib.oracle_sincos_array.argtypes = [_d, C.c_uint64, _d, _d]
         lib.oracle_pow5_array.argtypes = [_d, C.c_uint64, _d]
+        lib.oracle_log_array.argtypes = [_d, C.c_uint64, _d]
         lib.oracle_rng_array.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _d]
         lib.oracle_mt_array.argtypes = [C.c_uint64, _d]
         self.lib = lib
@@ -166,6 +167,12 @@ class Oracle:
         x = np.ascontiguousarray(x, dtype=np.float64)
         o = np.zeros_like(x)
         self.lib.oracle_pow5_array(x, len(x), o)
+        return o
+
+    def log(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        o = np.zeros_like(x)
+        self.lib.oracle_log_array(x, len(x), o)
         return o
 
     def rng(self, seed, pixel, sample, n):
