@@ -697,13 +697,21 @@ std::string build_composite_scene(const double* tv, const int32_t* tri_material,
         if (materials[tri_material[i]].type == BDPT_ISOTROPIC) return "isotropic is the phase function of a medium, not a surface material";
         precompute_triangle(tv + 9 * (size_t)i, tri_material[i], out.tris[i], out.aux[i], btris[i].box);
     }
-    uint32_t next_free = 0;
-    for (uint32_t k = 0; k < n_obj; k++) {
-        const bdpt_object& ob = objects[k];
+    // Objects may share a mesh (the same range: one bvh_node behind several wrappers, as shared_ptr allows in the
+    // reference); two different ranges must not overlap.
+    std::vector<uint32_t> by_first(n_obj);
+    for (uint32_t k = 0; k < n_obj; k++) by_first[k] = k;
+    std::stable_sort(by_first.begin(), by_first.end(), [objects](uint32_t a, uint32_t b) { return objects[a].first_triangle < objects[b].first_triangle; });
+    for (uint32_t q = 0; q < n_obj; q++) {
+        const bdpt_object& ob = objects[by_first[q]];
         if (ob.n_triangles == 0) return "object without triangles";
-        if (ob.first_triangle < next_free || (uint64_t)ob.first_triangle + ob.n_triangles > n_tri) return "object triangle ranges must be ascending, disjoint and inside the triangle array";
-        next_free = ob.first_triangle + ob.n_triangles;
-        for (uint32_t i = 0; i < ob.n_triangles; i++) out.tri_object[ob.first_triangle + i] = (int32_t)k;
+        if ((uint64_t)ob.first_triangle + ob.n_triangles > n_tri) return "object triangle range outside the triangle array";
+        if (q > 0) {
+            const bdpt_object& pv = objects[by_first[q - 1]];
+            const bool same = pv.first_triangle == ob.first_triangle && pv.n_triangles == ob.n_triangles;
+            if (!same && pv.first_triangle + pv.n_triangles > ob.first_triangle) return "object triangle ranges must be identical (a shared mesh) or disjoint";
+        }
+        for (uint32_t i = 0; i < ob.n_triangles; i++) out.tri_object[ob.first_triangle + i] = (int32_t)by_first[q];
         if (ob.flags & ~(kCxRotate | kCxTranslate | kCxMedium)) return "unknown object flag";
         if (ob.flags & kCxMedium) {
             if (ob.phase_material < 0 || (uint32_t)ob.phase_material >= n_mat || materials[ob.phase_material].type != BDPT_ISOTROPIC)
@@ -712,17 +720,25 @@ std::string build_composite_scene(const double* tv, const int32_t* tri_material,
     }
 
     // each object's own bvh_node(hittable_list of its triangles), and its box in the world
-    std::vector<std::vector<BuildNode>> obj_nodes(n_obj);
+    std::vector<std::vector<BuildNode>> obj_nodes(n_obj);     // filled for the first object of every mesh
+    std::vector<int32_t> mesh_of(n_obj, -1);                   // the object that built the mesh this object uses
     std::vector<Box3> obj_box(n_obj);
     out.objs.resize(n_obj);
-    for (uint32_t k = 0; k < n_obj; k++) {
+    for (uint32_t q = 0; q < n_obj; q++) {
+        const uint32_t k = by_first[q];
         const bdpt_object& ob = objects[k];
-        std::vector<BuildTri> local(btris.begin() + ob.first_triangle, btris.begin() + ob.first_triangle + ob.n_triangles);
-        Builder b(local);
-        b.order.resize(ob.n_triangles);
-        for (uint32_t i = 0; i < ob.n_triangles; i++) b.order[i] = i;
-        b.build(0, ob.n_triangles);
-        Box3 box = b.nodes[0].box;                              // bvh_node::bounding_box
+        if (q > 0 && objects[by_first[q - 1]].first_triangle == ob.first_triangle) {
+            mesh_of[k] = mesh_of[by_first[q - 1]];
+        } else {
+            mesh_of[k] = (int32_t)k;
+            std::vector<BuildTri> local(btris.begin() + ob.first_triangle, btris.begin() + ob.first_triangle + ob.n_triangles);
+            Builder b(local);
+            b.order.resize(ob.n_triangles);
+            for (uint32_t i = 0; i < ob.n_triangles; i++) b.order[i] = i;
+            b.build(0, ob.n_triangles);
+            obj_nodes[k].swap(b.nodes);
+        }
+        Box3 box = obj_nodes[mesh_of[k]][0].box;                // bvh_node::bounding_box
         CxObject& co = out.objs[k];
         co = CxObject();
         co.flags = ob.flags;
@@ -760,18 +776,25 @@ std::string build_composite_scene(const double* tv, const int32_t* tri_material,
             }
         }
         obj_box[k] = box;
-        obj_nodes[k].swap(b.nodes);
-        // the builder sorted local indices; leaf references become global triangle ids below
     }
 
-    // the world's list: triangles of no object and the objects, in the order of the triangle array
+    // the world's list: triangles of no object and the objects, each object at the place of its first triangle
+    // (objects that share a mesh in the order of their indices)
     std::vector<BuildTri> items;
     std::vector<int32_t> item_ref;
-    for (uint32_t i = 0; i < n_tri;) {
-        const int32_t k = out.tri_object[i];
-        BuildTri it;
-        if (k < 0) { it.box = btris[i].box; items.push_back(it); item_ref.push_back((int32_t)i); i++; }
-        else { it.box = obj_box[k]; items.push_back(it); item_ref.push_back(-((int32_t)k + 2)); i += objects[k].n_triangles; }
+    {
+        uint32_t q = 0;
+        for (uint32_t i = 0; i < n_tri;) {
+            BuildTri it;
+            if (out.tri_object[i] < 0) { it.box = btris[i].box; items.push_back(it); item_ref.push_back((int32_t)i); i++; continue; }
+            uint32_t span = 0;
+            while (q < n_obj && objects[by_first[q]].first_triangle == i) {
+                const uint32_t k = by_first[q++];
+                it.box = obj_box[k]; items.push_back(it); item_ref.push_back(-((int32_t)k + 2));
+                span = objects[k].n_triangles;
+            }
+            i += span;
+        }
     }
     Builder wb(items);
     wb.order.resize(items.size());
@@ -782,12 +805,14 @@ std::string build_composite_scene(const double* tv, const int32_t* tri_material,
     append_threaded(wb.nodes, item_ref, out.nodes, out.tree_depth, &out.world_leaves);
     out.n_world_nodes = (uint32_t)out.nodes.size();
     for (uint32_t k = 0; k < n_obj; k++) {
+        if (mesh_of[k] != (int32_t)k) continue;
         std::vector<int32_t> refs(objects[k].n_triangles);
         for (uint32_t i = 0; i < objects[k].n_triangles; i++) refs[i] = (int32_t)(objects[k].first_triangle + i);
         out.objs[k].root = (uint32_t)out.nodes.size();
         uint32_t d = 1;
         append_threaded(obj_nodes[k], refs, out.nodes, d, nullptr);
     }
+    for (uint32_t k = 0; k < n_obj; k++) out.objs[k].root = out.objs[mesh_of[k]].root;
 
     // the light collection: triangles of the world's list only
     if (n_lights == 0) {

@@ -260,6 +260,12 @@ class CompositeScene(FlatScene):
         self.objects.append(SceneObject(first, self.n_triangles - first, **kw))
         return len(self.objects) - 1
 
+    def add_instance(self, of: int, **kw) -> int:
+        """Another object over the mesh of object `of` (one bvh_node shared by several wrappers)."""
+        src = self.objects[of]
+        self.objects.append(SceneObject(src.first_triangle, src.n_triangles, **kw))
+        return len(self.objects) - 1
+
     def to_bytes(self) -> bytes:
         out = [b"BDPTSCN1", struct.pack("<4I", len(self.materials), self.n_triangles, len(self.lights), 0)]
         for m in self.materials:
@@ -343,6 +349,34 @@ def cornell_instances(image_width: int = 32, samples_per_pixel: int = 16, max_de
     f = s.begin_object(); _object_box(s, (300, 340, 200), (380, 420, 280), glass)
     s.end_object(f, flags=OBJECT_ROTATE_Y, rotate_y_degrees=8.0)
     s.camera = _cornell_camera(image_width, samples_per_pixel, max_depth, "cornell_instances.png")
+    return s
+
+
+def sphere_lattice_instanced(n_side: int = 22, image_width: int = 4096, samples_per_pixel: int = 64, max_depth: int = 10) -> CompositeScene:
+    """sphere_lattice as a host of the reference would write it with instances: six sphere meshes of 960 triangles (one
+    per colour), each a bvh_node of its own, and n_side^3 translate wrappers that share them (hittable.h:46-74).
+    n_side = 22: 10 648 instances standing for 10.2 M triangles."""
+    s = CompositeScene()
+    grey = s.add_material(Material(LAMBERTIAN, (.6, .6, .6)))
+    palette = [s.add_material(Material(LAMBERTIAN, c)) for c in
+               ((.75, .25, .25), (.25, .75, .25), (.25, .25, .75), (.7, .7, .2), (.2, .7, .7), (.7, .2, .7))]
+    light = s.add_material(Material(DIFFUSE_LIGHT, (40.0, 40.0, 40.0)))
+    extent = 3.0 * n_side
+    add_quad_triangles(s, (-extent, -1.5, -extent), (3 * extent, 0, 0), (0, 0, 3 * extent), grey)
+    add_quad_triangles(s, (0.25 * extent, 1.6 * extent, 0.25 * extent), (0.5 * extent, 0, 0), (0, 0, 0.5 * extent), light)
+    centers = [(3.0 * a, 3.0 * b, 3.0 * c) for a in range(n_side) for b in range(n_side) for c in range(n_side)]
+    first_of = {}
+    for k, ctr in enumerate(centers):
+        colour = k % len(palette)
+        if colour not in first_of:
+            f = s.begin_object()
+            add_uv_sphere(s, (0.0, 0.0, 0.0), 1.0, palette[colour])
+            first_of[colour] = s.end_object(f, flags=OBJECT_TRANSLATE, offset=ctr)
+        else:
+            s.add_instance(first_of[colour], flags=OBJECT_TRANSLATE, offset=ctr)
+    s.camera = Camera(aspect_ratio=1.0, image_width=image_width, samples_per_pixel=samples_per_pixel, max_depth=max_depth,
+                      background=(0.02, 0.02, 0.03), vfov=40.0, lookfrom=(-1.2 * extent, 1.4 * extent, -1.6 * extent),
+                      lookat=(0.5 * extent, 0.3 * extent, 0.5 * extent), vup=(0, 1, 0), file_name="sphere_lattice_instanced.png")
     return s
 
 

@@ -237,8 +237,9 @@ typedef struct bdpt_object {
 
 /* bdpt_scene_create for a world that also holds such objects.  The world's hittable_list is: the triangles that
  * belong to no object, each as its own entry, and the objects, each entry at the place of its first triangle -
- * i.e. the order of the triangle array; `bvh_node(list)` is built over it as in src/main.cpp:66.  Object ranges must
- * not overlap and must be in ascending order.  Light triangles (the `lights` collection) must be triangles that
+ * i.e. the order of the triangle array; `bvh_node(list)` is built over it as in src/main.cpp:66.  Two objects may name
+ * the SAME range: they share one mesh (one bvh_node behind several wrappers, as shared_ptr allows in the reference)
+ * and stand in the list in the order of their indices; different ranges must not overlap.  Light triangles (the `lights` collection) must be triangles that
  * belong to no object; n_lights == 0 selects all of those.
  * The resulting scene renders through every bdpt_render* entry point except bdpt_render_device_static, on the
  * single-kernel path (one thread per sample, the reference's own traversal order: constant_medium::hit draws its

@@ -165,27 +165,33 @@ static void build(const fs_scene& fs, built_scene& b, bool unique_materials, con
                 i++;
                 continue;
             }
-            const fs_object& ob = fs.objects[owner[i]];
+            // the mesh that starts here, once; every object that names this range wraps the same bvh_node
+            const uint32_t n_mesh = fs.objects[owner[i]].n_triangles;
             hittable_list mesh;
-            for (uint32_t q = 0; q < ob.n_triangles; q++) {
-                auto tp = make_shared<triangle>(b.world.tris[ob.first_triangle + q]);
-                b.leaf_ptrs[ob.first_triangle + q] = tp;
+            for (uint32_t q = 0; q < n_mesh; q++) {
+                auto tp = make_shared<triangle>(b.world.tris[i + q]);
+                b.leaf_ptrs[i + q] = tp;
                 mesh.add(tp);
             }
-            shared_ptr<hittable> h = make_shared<bvh_node>(mesh);
-            if (ob.flags & 1u) h = make_shared<rotate_y>(h, ob.rotate_y_degrees);
-            if (ob.flags & 2u) h = make_shared<translate>(h, vec3(ob.offset[0], ob.offset[1], ob.offset[2]));
-            if (ob.flags & 4u) {
-                const fs_material& pm = fs.materials[ob.phase_material];
-                shared_ptr<constant_medium> cm = (pm.pad > 0)
-                    ? make_shared<constant_medium>(h, ob.density, g_textures.at(pm.pad - 1))
-                    : make_shared<constant_medium>(h, ob.density, color(pm.rgb[0], pm.rgb[1], pm.rgb[2]));
-                b.phase[owner[i]] = cm->phase_function.get();
-                h = cm;
+            shared_ptr<hittable> shared_mesh = make_shared<bvh_node>(mesh);
+            for (uint32_t k = 0; k < fs.n_objects; k++) {
+                const fs_object& ob = fs.objects[k];
+                if (ob.first_triangle != i) continue;
+                shared_ptr<hittable> h = shared_mesh;
+                if (ob.flags & 1u) h = make_shared<rotate_y>(h, ob.rotate_y_degrees);
+                if (ob.flags & 2u) h = make_shared<translate>(h, vec3(ob.offset[0], ob.offset[1], ob.offset[2]));
+                if (ob.flags & 4u) {
+                    const fs_material& pm = fs.materials[ob.phase_material];
+                    shared_ptr<constant_medium> cm = (pm.pad > 0)
+                        ? make_shared<constant_medium>(h, ob.density, g_textures.at(pm.pad - 1))
+                        : make_shared<constant_medium>(h, ob.density, color(pm.rgb[0], pm.rgb[1], pm.rgb[2]));
+                    b.phase[k] = cm->phase_function.get();
+                    h = cm;
+                }
+                b.objects[k] = h;
+                list.add(h);
             }
-            b.objects[owner[i]] = h;
-            list.add(h);
-            i += ob.n_triangles;
+            i += n_mesh;
         }
         // the light collection: the listed triangles, or every triangle of the world's list
         if (fs.n_lights > 0) { loose.clear(); for (uint32_t i = 0; i < fs.n_lights; i++) loose.push_back(fs.lights[i]); }

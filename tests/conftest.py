@@ -63,6 +63,7 @@ COMPOSITE_CASES = {
     "cx_instances": lambda s: s.cornell_instances(32, 16, 8),
     "cx_textures": lambda s: s.cornell_textures(32, 16, 8),
     "cx_smoke": lambda s: s.cornell_smoke(32, 16, 8),
+    "cx_lattice": lambda s: s.sphere_lattice_instanced(3, 32, 16, 8),       # translate wrappers that share meshes
 }
 
 

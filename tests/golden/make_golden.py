@@ -367,6 +367,8 @@ def composite_fixtures(tmp):
     golden_composite("cx_instances", scenes.cornell_instances(32, 16, 8), tmp, seed=31, n_rays=2048, n_pairs=1024, sample_crop=(8, 8, 24, 24))
     golden_composite("cx_textures", scenes.cornell_textures(32, 16, 8), tmp, seed=32, n_rays=2048, n_pairs=1024, sample_crop=(8, 8, 24, 24))
     golden_composite("cx_smoke", scenes.cornell_smoke(32, 16, 8), tmp, seed=33, n_rays=2048, n_pairs=1024, sample_crop=(8, 8, 24, 24))
+    # 27 translate wrappers over six shared sphere meshes
+    golden_composite("cx_lattice", scenes.sphere_lattice_instanced(3, 32, 16, 8), tmp, seed=34, n_rays=2048, n_pairs=1024, sample_crop=(8, 8, 24, 24))
 
 
 def golden_unidirectional(name, scene, tmp, *, seed):
