@@ -234,14 +234,14 @@ int render_megakernel(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_cam
 
 // ---- composite scenes: the same single-kernel scheme over the scene's own tables (composite.hip)
 int render_composite(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam, uint64_t seed, const int32_t* rows,
-                     int32_t n_rows, int x0, int x1, int64_t n_owned, double* d_fb, bool stats, hipStream_t stream) {
+                     int32_t n_rows, int x0, int x1, int64_t n_owned, double* d_fb, bool stats, bool unidirectional, hipStream_t stream) {
     HIP_TRY(hipMemsetAsync(ctx->unit_counter, 0, sizeof(uint32_t), stream));
     const int spp = cam->sqrt_spp * cam->sqrt_spp;
     const int ppg = spp >= kBlock ? 1 : kBlock / spp;
     const int64_t n_units = (n_owned + ppg - 1) / ppg;
     if (n_units > 0x7FFFFFFF) return fail(BDPT_ERR_INVALID_ARGUMENT, "too many work units in one call");
     int per_cu = 1;
-    HIP_TRY(cx_render_blocks_per_cu(stats, &per_cu));
+    HIP_TRY(cx_render_blocks_per_cu(stats, unidirectional, &per_cu));
     int64_t grid = (int64_t)ctx->cu_count * per_cu;
     if (grid > n_units) grid = n_units;
     const size_t ws_stride = (size_t)grid * kBlock;
@@ -260,7 +260,7 @@ int render_composite(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     rl.vertex_ws = ctx->vertex_ws;
     rl.stats = stats ? ctx->stats : nullptr;
     rl.ws_stride = ws_stride;
-    HIP_TRY(cx_launch_render(scene->cx_dev, to_gpu_camera(*cam), rl, (int)grid, stats, stream));
+    HIP_TRY(cx_launch_render(scene->cx_dev, to_gpu_camera(*cam), rl, (int)grid, stats, unidirectional, stream));
     return BDPT_OK;
 }
 
@@ -575,7 +575,6 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     // path, which also takes over when the four-wide hierarchy is deeper than the pipeline's traversal stack.
     // Everything else runs the wavefront pipeline unless the caller asks otherwise.
     const bool single_kernel = scene->composite || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || !pipeline_can_walk(scene);
-    if (scene->composite && unidirectional) return fail(BDPT_ERR_UNSUPPORTED, "BDPT_RENDER_UNIDIRECTIONAL is not available for composite scenes");
     if (scene->composite && fixed_ws) return fail(BDPT_ERR_UNSUPPORTED, "composite scenes render on the single-kernel path, which allocates");
     if (fixed_ws && (single_kernel || time_stages))
         return fail(BDPT_ERR_UNSUPPORTED, pipeline_can_walk(scene)
@@ -608,7 +607,7 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
         const int64_t n_owned = n_rows * (x1 - x0);
         int rc;
         if (scene->composite)
-            rc = render_composite(ctx, scene, cam, p->seed, rows, (int32_t)n_rows, x0, x1, n_owned, d_fb, want_stats, stream);
+            rc = render_composite(ctx, scene, cam, p->seed, rows, (int32_t)n_rows, x0, x1, n_owned, d_fb, want_stats, unidirectional, stream);
         else if (single_kernel)
             rc = render_megakernel(ctx, scene, cam, p->seed, rows, (int32_t)n_rows, x0, x1, n_owned, d_fb, stats_mode, unidirectional, stream);
         else
@@ -937,6 +936,9 @@ int bdpt_scene_create_composite(bdpt_context* ctx, const double* tri_vertices, c
     d.n_lights = h.n_lights;
     d.n_objs = (uint32_t)h.objs.size();
     d.n_tex = (uint32_t)h.tex.size();
+    d.n_media = 0;
+    for (const CxObject& ob : h.objs) d.n_media += (ob.flags & kCxMedium) ? 1u : 0u;
+    d.pad = 0;
     *out = s;
     return BDPT_OK;
 }

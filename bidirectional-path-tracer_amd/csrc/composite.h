@@ -60,6 +60,8 @@ struct CxSceneDev {
     const double* light_accum;
     double light_total_area;
     uint32_t n_nodes, n_tris, n_mats, n_lights, n_objs, n_tex;
+    uint32_t n_media;              // objects that are a constant_medium: with none, a visibility query may stop at the first hit
+    uint32_t pad;
 };
 
 struct CxHostScene {
@@ -104,9 +106,10 @@ struct CxRenderLaunch {
 };
 constexpr int kCxVtxDoubles = 13;   // p[3] n[3] T[3] f[3] + flags
 
-hipError_t cx_render_blocks_per_cu(bool stats, int* out);
+// unidirectional: camera::path_trace_color instead of bidirectional_color
+hipError_t cx_render_blocks_per_cu(bool stats, bool unidirectional, int* out);
 hipError_t cx_launch_render(const CxSceneDev& sc, const GpuCamera& cam, const CxRenderLaunch& rl, int grid_blocks, bool stats,
-                            hipStream_t stream);
+                            bool unidirectional, hipStream_t stream);
 hipError_t cx_launch_trace_closest(const CxSceneDev& sc, const double* d_rays, uint64_t n, double* d_hits,
                                    unsigned long long* d_stats, hipStream_t stream);
 hipError_t cx_launch_visible(const CxSceneDev& sc, const double* d_pairs, uint64_t n, uint8_t* d_out, hipStream_t stream);

@@ -21,7 +21,9 @@ struct CxHit {
 };
 
 // bvh_node::hit (src/acceleration/bvh.h:50-59) over ONE tree of triangles, starting at record `root`
-template <int STATS>
+// ANYHIT (visibility rays of a scene without media, not counting): returns at the first accepted triangle - the
+// boolean the reference derives from its full closest-hit query (camera.h:437) is the same.
+template <int STATS, bool ANYHIT = false>
 BDPT_DEV bool cx_walk_mesh(const CxSceneDev& sc, uint32_t root, V3 o, V3 d, double tmin, double tmax, CxHit& hit, Counters& c) {
     const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;                 // aabb.h:48
     double closest = tmax;
@@ -54,12 +56,12 @@ BDPT_DEV bool cx_walk_mesh(const CxSceneDev& sc, uint32_t root, V3 o, V3 d, doub
                 const bool h = tri_test(sc.tris[nd.tri0], o, d, tmin, closest, t, u, v);
                 const bool twice = (nd.tri1 == nd.tri0);             // one-triangle node: tested twice, same outcome
                 if (STATS) { c.tri_tests += twice ? 2 : 1; if (h) c.tri_hits += twice ? 2 : 1; }
-                if (h) { closest = t; hit.t = t; hit.u = u; hit.v = v; hit.tri = nd.tri0; any = true; }
+                if (h) { if (ANYHIT) return true; closest = t; hit.t = t; hit.u = u; hit.v = v; hit.tri = nd.tri0; any = true; }
             }
             if (nd.tri1 != nd.tri0) {
                 const bool h = tri_test(sc.tris[nd.tri1], o, d, tmin, closest, t, u, v);
                 if (STATS) { c.tri_tests++; if (h) c.tri_hits++; }
-                if (h) { closest = t; hit.t = t; hit.u = u; hit.v = v; hit.tri = nd.tri1; any = true; }
+                if (h) { if (ANYHIT) return true; closest = t; hit.t = t; hit.u = u; hit.v = v; hit.tri = nd.tri1; any = true; }
             }
         }
         i = nd.next;
@@ -78,14 +80,14 @@ BDPT_DEV void cx_to_object(const CxObject& ob, V3& o, V3& d) {
 }
 
 // hit() of one object of the world's list
-template <int STATS>
+template <int STATS, bool ANYHIT = false>
 BDPT_DEV bool cx_object_hit(const CxSceneDev& sc, int32_t k, V3 o, V3 d, double tmin, double tmax, CxHit& hit, Counters& c, Rng& rng) {
     const CxObject ob = sc.objs[k];
     V3 oo = o, od = d;
     cx_to_object(ob, oo, od);
     if (!(ob.flags & kCxMedium)) {
         CxHit h;
-        if (!cx_walk_mesh<STATS>(sc, ob.root, oo, od, tmin, tmax, h, c)) return false;
+        if (!cx_walk_mesh<STATS, ANYHIT>(sc, ob.root, oo, od, tmin, tmax, h, c)) return false;
         hit = h;
         hit.obj = k;
         return true;
@@ -111,7 +113,7 @@ BDPT_DEV bool cx_object_hit(const CxSceneDev& sc, int32_t k, V3 o, V3 d, double 
 }
 
 // bvh_node::hit over the world's tree: leaves are triangles or objects
-template <int STATS>
+template <int STATS, bool ANYHIT = false>
 BDPT_DEV bool cx_walk(const CxSceneDev& sc, V3 o, V3 d, double tmin, double tmax, CxHit& hit, Counters& c, Rng& rng) {
     const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;
     double closest = tmax;
@@ -147,10 +149,10 @@ BDPT_DEV bool cx_walk(const CxSceneDev& sc, V3 o, V3 d, double tmin, double tmax
                     double t, u, v;
                     const bool h = tri_test(sc.tris[ref], o, d, tmin, closest, t, u, v);
                     if (STATS) { c.tri_tests++; if (h) c.tri_hits++; }
-                    if (h) { closest = t; hit.t = t; hit.u = u; hit.v = v; hit.tri = ref; hit.obj = -1; any = true; }
+                    if (h) { if (ANYHIT) return true; closest = t; hit.t = t; hit.u = u; hit.v = v; hit.tri = ref; hit.obj = -1; any = true; }
                 } else {
                     CxHit h;
-                    if (cx_object_hit<STATS>(sc, -(ref + 2), o, d, tmin, closest, h, c, rng)) { closest = h.t; hit = h; any = true; }
+                    if (cx_object_hit<STATS, ANYHIT>(sc, -(ref + 2), o, d, tmin, closest, h, c, rng)) { if (ANYHIT) return true; closest = h.t; hit = h; any = true; }
                 }
             }
         }
@@ -422,7 +424,9 @@ BDPT_DEV V3 cx_connect(const CxSceneDev& sc, const CxVertex& cv, const CxVertex&
     if (max_t <= 0) return mk(0, 0, 0);
     if (STATS) c.shadow_rays++;
     CxHit tmp;
-    if (cx_walk<STATS>(sc, origin, dir_unit, 0.001, max_t, tmp, c, rng)) return mk(0, 0, 0);
+    const bool blocked = (STATS == kStatsOff && sc.n_media == 0) ? cx_walk<kStatsOff, true>(sc, origin, dir_unit, 0.001, max_t, tmp, c, rng)
+                                                                 : cx_walk<STATS>(sc, origin, dir_unit, 0.001, max_t, tmp, c, rng);
+    if (blocked) return mk(0, 0, 0);
     const V3 f_cam = (cv.flags & kCxIsLight) ? mk(0, 0, 0) : cv.f;          // evaluate_bsdf of an emitter, material.h:35-37
     if (len2(f_cam) <= 0) return mk(0, 0, 0);
     const V3 f_light = lv.f;
@@ -513,6 +517,98 @@ BDPT_DEV V3 cx_sample_radiance(const CxSceneDev& sc, const GpuCamera& cam, int i
     return result;
 }
 
+// ------------------------------------------------------------------ unidirectional estimator
+// triangle::pdf_value, triangle.h:78-91, of one triangle of the light collection
+template <int STATS>
+BDPT_DEV double cx_light_tri_pdf(const CxSceneDev& sc, uint32_t tri_id, V3 origin, V3 direction, Counters& c) {
+    double t, u, v;
+    if (STATS) c.tri_tests++;
+    if (!tri_test(sc.tris[tri_id], origin, direction, 0.001, kInf, t, u, v)) return 0.0;
+    if (STATS) c.tri_hits++;
+    const GpuTriAux ax = sc.aux[tri_id];
+    const V3 outward = ld3(ax.normal);
+    const V3 normal = (dot(direction, outward) < 0) ? outward : neg(outward);
+    const double distance_squared = t * t * len2(direction);
+    const double cosine = __builtin_fabs(dot(direction, normal) / len(direction));
+    if (ax.area <= 0.0 || cosine <= 0.0) return 0.0;
+    return distance_squared / (cosine * ax.area);
+}
+
+// camera::path_trace_color, camera.h:255-292, as in sample_radiance_unidirectional of device_core.h: the walk goes
+// forward keeping one record per level (factor in p, pdf in n.x, 0 marking `attenuation * sample`) and the
+// expressions of the returning recursion are folded from the last level to the first.  Beside the lambertian
+// surface, the phase function of a medium mixes the light collection with its own sphere_pdf (pdf.h:17-28,70-87).
+template <int STATS>
+BDPT_DEV V3 cx_sample_radiance_unidirectional(const CxSceneDev& sc, const GpuCamera& cam, int i, int j, int s_i, int s_j,
+                                              uint64_t seed, const CxVertexStore& store, Counters& c, uint32_t& draws) {
+    Rng rng;
+    rng.key = stream_key(seed, (uint64_t)j * (uint64_t)cam.width + (uint64_t)i, (uint64_t)s_j * cam.sqrt_spp + s_i);
+    rng.counter = 0;
+    V3 o, d;
+    camera_ray(cam, i, j, s_i, s_j, rng, o, d);
+    int n = 0;
+    V3 result = mk(0, 0, 0);
+    for (int remaining = cam.max_depth;; remaining--) {
+        if (STATS) c.rays_traced++;
+        if (remaining <= 0) break;                                        // camera.h:258-259
+        CxHit h;
+        if (!cx_walk<STATS>(sc, o, d, 0.001, kInf, h, c, rng)) { result = ld3(cam.background); break; }
+        CxSurf s;
+        cx_surface(sc, o, d, h, s);
+        const GpuMaterial m = sc.mats[s.mat];
+        if (m.type == BDPT_DIFFUSE_LIGHT) { result = s.front ? cx_colour(sc, m, s.u, s.v, s.p) : mk(0, 0, 0); break; }
+        CxVertex rec;
+        rec.n = mk(0, 0, 0); rec.T = mk(0, 0, 0); rec.f = mk(0, 0, 0); rec.flags = 0;
+        if (m.type == BDPT_METAL || m.type == BDPT_DIELECTRIC) {
+            CxBounce bo;
+            cx_bounce<true>(sc, o, d, h, mk(1.0, 1.0, 1.0), rng, bo);      // bo.T = 1 * attenuation
+            rec.p = bo.T;
+            store.put(n++, rec);
+            o = bo.o; d = bo.d;
+            continue;
+        }
+        const bool iso = (m.type == BDPT_ISOTROPIC);
+        const V3 attenuation = cx_colour(sc, m, s.u, s.v, s.p);
+        V3 w;
+        (void)onb_transform(s.n, mk(0, 0, 0), w);                          // cosine_pdf's basis (pdf.h:34)
+        V3 direction;
+        if (rng.next() < 0.5) {                                            // mixture_pdf::generate, pdf.h:80-85
+            int idx = (int)(0.0 + ((double)(int)sc.n_lights - 0.0) * rng.next());      // triangle.h:187, main.h:34-42
+            if (idx > (int)sc.n_lights - 1) idx = (int)sc.n_lights - 1;
+            const GpuTri lt = sc.tris[sc.light_tris[idx]];
+            double u = rng.next();
+            double v = rng.next();
+            if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
+            const V3 lp = add(add(ld3(lt.v0), scl(u, ld3(lt.e1))), scl(v, ld3(lt.e2)));
+            direction = sub(lp, s.p);
+        } else if (iso) {
+            direction = random_unit_vector(rng);
+        } else {
+            V3 w2;
+            direction = onb_transform(s.n, random_cosine_direction(rng), w2);
+        }
+        const double weight = 1.0 / (double)sc.n_lights;                    // triangle.h:170-181
+        double sum = 0.0;
+        for (uint32_t k = 0; k < sc.n_lights; k++) sum += weight * cx_light_tri_pdf<STATS>(sc, sc.light_tris[k], s.p, direction, c);
+        const double own = iso ? 1 / (4 * kPi) : __builtin_fmax(0.0, dot(unit(direction), w) / kPi);
+        const double pdf_value = 0.5 * sum + 0.5 * own;
+        if (pdf_value <= 0) break;                                         // returns the (zero) emission of the surface
+        double scattering_pdf;
+        if (iso) scattering_pdf = 1 / (4 * kPi);
+        else { const double cos_theta = dot(s.n, unit(direction)); scattering_pdf = cos_theta < 0 ? 0 : cos_theta / kPi; }
+        rec.p = scl(scattering_pdf, attenuation);
+        rec.n.x = pdf_value;
+        store.put(n++, rec);
+        o = s.p; d = direction;
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        const CxVertex rec = store.get(k);
+        result = (rec.n.x == 0.0) ? mulv(rec.p, result) : add(mk(0, 0, 0), divs(mulv(rec.p, result), rec.n.x));
+    }
+    draws = rng.counter;
+    return result;
+}
+
 __device__ __forceinline__ void cx_flush_counters(const Counters& c, uint32_t draws, uint32_t samples, unsigned long long* stats) {
     unsigned long long v[11] = {c.rays_traced, c.aabb_tests, c.aabb_hits, c.node_visits, c.tri_tests,
                                 c.tri_hits,    c.shadow_rays, c.pairs,    draws,         samples,       c.vertices};
@@ -528,7 +624,7 @@ __device__ __forceinline__ void cx_flush_counters(const Counters& c, uint32_t dr
 // Persistent workgroups; a work unit is `pixels_per_group` consecutive owned pixels, a thread renders one sample and
 // the per-pixel sum is formed in the reference's order (s_j outer, s_i inner, camera.h:118-123) by one lane per
 // colour channel reading the samples from LDS.
-template <int STATS>
+template <int STATS, bool UNIDIRECTIONAL>
 __global__ __launch_bounds__(kBlock) void cx_render_kernel(CxSceneDev sc, GpuCamera cam, CxRenderLaunch rl) {
     __shared__ double l_samples[kBlock * 3];
     __shared__ double l_carry[kBlock * 3];
@@ -567,7 +663,8 @@ __global__ __launch_bounds__(kBlock) void cx_render_kernel(CxSceneDev sc, GpuCam
                 const int i = rl.x0 + (int)(q % row_w);
                 const int s_j = s / cam.sqrt_spp, s_i = s - s_j * cam.sqrt_spp;
                 uint32_t draws = 0;
-                col = cx_sample_radiance<STATS>(sc, cam, i, j, s_i, s_j, rl.seed, store, c, draws);
+                col = UNIDIRECTIONAL ? cx_sample_radiance_unidirectional<STATS>(sc, cam, i, j, s_i, s_j, rl.seed, store, c, draws)
+                                     : cx_sample_radiance<STATS>(sc, cam, i, j, s_i, s_j, rl.seed, store, c, draws);
                 total_draws += draws;
                 total_samples++;
             }
@@ -645,7 +742,9 @@ __global__ __launch_bounds__(kBlock) void cx_visible_kernel(CxSceneDev sc, const
             const double max_t = dist - 0.001;
             if (max_t > 0) {
                 CxHit tmp;
-                vis = cx_walk<kStatsOff>(sc, origin, dir_unit, 0.001, max_t, tmp, c, rng) ? 0 : 1;
+                const bool blocked = (sc.n_media == 0) ? cx_walk<kStatsOff, true>(sc, origin, dir_unit, 0.001, max_t, tmp, c, rng)
+                                                       : cx_walk<kStatsOff>(sc, origin, dir_unit, 0.001, max_t, tmp, c, rng);
+                vis = blocked ? 0 : 1;
             }
         }
         out[r] = vis;
@@ -654,19 +753,27 @@ __global__ __launch_bounds__(kBlock) void cx_visible_kernel(CxSceneDev sc, const
 
 }  // namespace
 
-hipError_t cx_render_blocks_per_cu(bool stats, int* out) {
+hipError_t cx_render_blocks_per_cu(bool stats, bool unidirectional, int* out) {
     int n = 0;
-    hipError_t e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cx_render_kernel<kStatsReference>, kBlock, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cx_render_kernel<kStatsOff>, kBlock, 0);
+    hipError_t e;
+    if (unidirectional) e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cx_render_kernel<kStatsReference, true>, kBlock, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cx_render_kernel<kStatsOff, true>, kBlock, 0);
+    else e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cx_render_kernel<kStatsReference, false>, kBlock, 0)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cx_render_kernel<kStatsOff, false>, kBlock, 0);
     *out = n < 1 ? 1 : n;
     return e;
 }
 
 hipError_t cx_launch_render(const CxSceneDev& sc, const GpuCamera& cam, const CxRenderLaunch& rl, int grid_blocks, bool stats,
-                            hipStream_t stream) {
+                            bool unidirectional, hipStream_t stream) {
     dim3 grid(grid_blocks), block(kBlock);
-    if (stats) hipLaunchKernelGGL((cx_render_kernel<kStatsReference>), grid, block, 0, stream, sc, cam, rl);
-    else hipLaunchKernelGGL((cx_render_kernel<kStatsOff>), grid, block, 0, stream, sc, cam, rl);
+    if (unidirectional) {
+        if (stats) hipLaunchKernelGGL((cx_render_kernel<kStatsReference, true>), grid, block, 0, stream, sc, cam, rl);
+        else hipLaunchKernelGGL((cx_render_kernel<kStatsOff, true>), grid, block, 0, stream, sc, cam, rl);
+    } else {
+        if (stats) hipLaunchKernelGGL((cx_render_kernel<kStatsReference, false>), grid, block, 0, stream, sc, cam, rl);
+        else hipLaunchKernelGGL((cx_render_kernel<kStatsOff, false>), grid, block, 0, stream, sc, cam, rl);
+    }
     return hipGetLastError();
 }
 

@@ -246,7 +246,7 @@ typedef struct bdpt_object {
  * random number INSIDE the BVH walk, constant_medium.h:40, so the visiting order is part of the result) and answers
  * bdpt_trace_closest* / bdpt_visible; query i draws from stream (seed 0, pixel i, sample 0).  A hit inside a
  * medium reports -(2 + object index) as its triangle id and u = v = 0 (the reference leaves them unset).
- * BDPT_RENDER_UNIDIRECTIONAL is not available for composite scenes.  An isotropic material with an image texture
+ * BDPT_RENDER_UNIDIRECTIONAL selects camera::path_trace_color as for other scenes.  An isotropic material with an image texture
  * is refused: the reference reads unset u, v there (constant_medium.h:45-50, material.h:155). */
 int bdpt_scene_create_composite(bdpt_context* ctx, const double* tri_vertices, const int32_t* tri_material,
                                 uint32_t n_triangles, const bdpt_material* materials, uint32_t n_materials,

@@ -356,6 +356,10 @@ def golden_composite(name, scene, tmp, *, seed, n_rays, n_pairs, sample_crop=Non
         run(HARNESS, spath, "samples", seed, sx0, sy0, sx1, sy1, o("smp"))
         g["sample_rect"] = np.array(sample_crop, dtype=np.int32)
         g["samples"] = rd(o("smp")).reshape(-1, 4)
+    # camera::path_trace_color (src/camera.h:255-292) over the same world and light collection
+    run(HARNESS, spath, "render_uni", seed, 0, 0, W, H, o("ufb"), o("ustats"))
+    g["uni_framebuffer"] = rd(o("ufb")).reshape(H, W, 3)
+    g["uni_render_stats"] = rd(o("ustats")).astype(np.uint64)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **g)
     hit = g["hits"][:, 0]
     print(name, "ok:", scene.n_triangles, "triangles,", len(scene.objects), "objects | hits: %d surface, %d in a medium, %d miss | visible %d of %d | mean %.4f"

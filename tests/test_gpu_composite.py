@@ -106,6 +106,22 @@ def test_render_matches_reference_bit_for_bit(case):
     assert d["rng_draws"] == int(g["render_stats"][7]), name + ": random draws (media draw inside the walk, shadow rays included)"
 
 
+def test_unidirectional_render_matches_reference(case):
+    """camera::path_trace_color (src/camera.h:255-292) over the composite world: mixture of the light collection with the
+    cosine pdf of a lambertian surface or the sphere pdf of a medium's phase function (src/acceleration/pdf.h:17-90)."""
+    name, flat, sc, g = case
+    cam = capi.camera_initialize(flat.camera)
+    seed = int(g["render_seed"][0])
+    fb = sc.render(cam, seed=seed, unidirectional=True)
+    assert_bit_equal(fb, g["uni_framebuffer"], name + ": framebuffer")
+    fb2, st = sc.render(cam, seed=seed, unidirectional=True, want_stats=True)
+    assert_bit_equal(fb2, g["uni_framebuffer"], name + ": framebuffer of the counting kernel")
+    d = st.as_dict()
+    got = [d["rays_traced"], d["aabb_tests"], d["aabb_hits"], d["bvh_node_visits"], d["triangle_tests"], d["triangle_hits"]]
+    assert got == [int(v) for v in g["uni_render_stats"][:6]], name + ": BvhStats"
+    assert d["rng_draws"] == int(g["uni_render_stats"][7]), name + ": random draws"
+
+
 def test_samples_match_reference(case):
     """Per-sample colours: a one-sample-per-pixel render of a crop cannot reproduce them (streams are per sample), so
     the crop is rendered whole and compared pixel by pixel with the sums of the reference's per-sample colours."""
@@ -133,12 +149,6 @@ def test_sharded_render_sums_to_the_whole(case):
 
 
 def test_refusals(ctx, scenes):
-    flat, g = composite_scene(scenes, "cx_smoke")
-    sc = ctx.scene(flat)
-    cam = capi.camera_initialize(flat.camera)
-    with pytest.raises(capi.BdptError, match="UNIDIRECTIONAL"):
-        sc.render(cam, unidirectional=True)
-    sc.close()
     bad, _ = composite_scene(scenes, "cx_textures")
     bad.materials[0].type = scenes.ISOTROPIC          # a surface triangle with a phase function
     with pytest.raises(capi.BdptError, match="isotropic"):
