@@ -92,6 +92,19 @@ struct GpuCamera {
     double defocus_angle;
 };
 
+constexpr uint32_t kCxRotate = 1u, kCxTranslate = 2u, kCxMedium = 4u;
+
+// One object of the world's list (src/objects/hittable.h:46-157, src/materials/volumes/constant_medium.h).
+struct CxObject {
+    double sin_theta, cos_theta;   // rotate_y::rotate_y, hittable.h:79-81
+    double offset[3];              // translate
+    double neg_inv_density;        // constant_medium.h:11
+    uint32_t root;                 // first record of the object's own bvh_node tree in the node table
+    uint32_t flags;                // kCx*
+    int32_t phase_material;
+    uint32_t pad;
+};
+
 struct SceneDev {
     const GpuNode* nodes;
     const GpuTri* tris;
@@ -115,6 +128,16 @@ struct SceneDev {
     double bary_margin;             // a hit closer than this (in barycentric units) to its triangle's outline is re-checked
     uint32_t n_nodes, n_tris, n_mats, n_lights;
     uint32_t ref_nested;            // 1: every box of `nodes` contains the boxes of the nodes below it
+    // Scenes with instances (translate / rotate_y objects over meshes of their own) on the pipeline.  `nodes` and
+    // `node_parent` then hold the two-level table of such a scene (the world's tree, whose leaves are triangles or
+    // objects, followed by one tree per mesh; every tree threaded by itself), `tris` of a mesh are in the mesh's own
+    // coordinates, an entry of `stris` / `xtris` is a (object, triangle) pair, `sleaf` the node of its own tree that
+    // holds the triangle, and `tri_pos` of a mesh triangle its rank inside the mesh (position = obj_pos0 + rank).
+    const CxObject* objs;           // null: no instances
+    const int32_t* xobj;            // per entry of `xtris`: the object whose ray transform its triangle test needs, -1: none
+    const int32_t* pos_obj;         // the same per entry of `stris`
+    const uint32_t* obj_leaf;       // per object: the node of the world's tree that holds it (| bit 31 = ref_nested)
+    const uint32_t* obj_pos0;       // per object: position in `stris` of the first triangle of its mesh
 };
 
 struct RenderLaunch {

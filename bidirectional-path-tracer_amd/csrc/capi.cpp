@@ -129,6 +129,9 @@ struct bdpt_scene {
     bool composite = false;
     CxHostScene cx_host;
     CxSceneDev cx_dev{};
+    void* d_cx_blob = nullptr;
+    size_t cx_blob_bytes = 0;
+    bool pipeline = true;          // false: a composite scene that only the single-kernel path can render (media, textures)
     void* d_blob = nullptr;
     size_t blob_bytes = 0;
     uint32_t n_materials = 0;
@@ -270,6 +273,8 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     cfg.lds_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuQuadNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
     cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
     if (!cfg.lds_scene) cfg.lds_bytes = 0;
+    cfg.instanced = scene->dev.objs != nullptr;
+    if (cfg.instanced) { cfg.lds_scene = false; cfg.lds_bytes = 0; }      // (the staged variants carry no instance code)
     cfg.own_test = cfg.lds_scene;
     cfg.ref_tree_bytes = cfg.lds_scene ? (((size_t)scene->dev.n_nodes * (sizeof(GpuNode) + sizeof(uint32_t)) + 15) & ~(size_t)15) : 0;
     cfg.top_nodes = (uint32_t)kn.lds_kb * 1024u / 128u;
@@ -574,8 +579,9 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     // Reference-equivalent counters need the reference's traversal of every shadow ray: that is the single-kernel
     // path, which also takes over when the four-wide hierarchy is deeper than the pipeline's traversal stack.
     // Everything else runs the wavefront pipeline unless the caller asks otherwise.
-    const bool single_kernel = scene->composite || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || !pipeline_can_walk(scene);
-    if (scene->composite && fixed_ws) return fail(BDPT_ERR_UNSUPPORTED, "composite scenes render on the single-kernel path, which allocates");
+    const bool cx_single = scene->composite && (!scene->pipeline || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || unidirectional || !pipeline_can_walk(scene));
+    const bool single_kernel = cx_single || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || !pipeline_can_walk(scene);
+    if (cx_single && fixed_ws) return fail(BDPT_ERR_UNSUPPORTED, "this composite scene renders on the single-kernel path, which allocates");
     if (fixed_ws && (single_kernel || time_stages))
         return fail(BDPT_ERR_UNSUPPORTED, pipeline_can_walk(scene)
                         ? "bdpt_render_device_static supports the flags BDPT_RENDER_COUNT_WORK, BDPT_RENDER_TIME_KERNEL and BDPT_RENDER_UNIDIRECTIONAL only"
@@ -606,7 +612,7 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
         HIP_TRY(wf_fill_rows(rows, y0, y1, shard_rows, shard_count, p->shard_index, stream));
         const int64_t n_owned = n_rows * (x1 - x0);
         int rc;
-        if (scene->composite)
+        if (cx_single)
             rc = render_composite(ctx, scene, cam, p->seed, rows, (int32_t)n_rows, x0, x1, n_owned, d_fb, want_stats, unidirectional, stream);
         else if (single_kernel)
             rc = render_megakernel(ctx, scene, cam, p->seed, rows, (int32_t)n_rows, x0, x1, n_owned, d_fb, stats_mode, unidirectional, stream);
@@ -675,6 +681,97 @@ int visible_pipeline(bdpt_context* ctx, const bdpt_scene* scene, const double* d
         HIP_TRY(wf_occlude(scene->dev, wb, nullptr, m, cursor, cfg, nullptr, stream));
         HIP_TRY(wf_visible_out(wb, m, d_out + first, stream));
     }
+    return BDPT_OK;
+}
+
+// Uploads s->host as one device allocation (tables at 256-byte aligned offsets) and fills s->dev.
+int upload_pipeline_tables(bdpt_context* ctx, bdpt_scene* s) {
+    (void)ctx;
+    const HostScene& h = s->host;
+    // one device allocation, tables at 256-byte aligned offsets
+    size_t off_nodes = 0;
+    size_t off_tris = off_nodes + align256(h.nodes.size() * sizeof(GpuNode));
+    size_t off_np = off_tris + align256(h.tris.size() * sizeof(GpuTri));
+    size_t off_st = off_np + align256(h.node_parent.size() * sizeof(uint32_t));
+    size_t off_sl = off_st + align256(h.stris.size() * sizeof(GpuTri));
+    size_t off_xn = off_sl + align256(h.sleaf.size() * sizeof(uint32_t));
+    size_t off_xt = off_xn + align256(h.xnodes.size() * sizeof(GpuQuadNode));
+    size_t off_aux = off_xt + align256(h.xtris.size() * sizeof(GpuTri));
+    size_t off_mats = off_aux + align256(h.aux.size() * sizeof(GpuTriAux));
+    size_t off_ltri = off_mats + align256(h.mats.size() * sizeof(GpuMaterial));
+    size_t off_lacc = off_ltri + align256(h.light_tris.size() * sizeof(uint32_t));
+    size_t off_tleaf = off_lacc + align256(h.light_accum.size() * sizeof(double));
+    size_t off_tgraze = off_tleaf + align256(h.tri_leaf.size() * sizeof(uint32_t));
+    size_t off_shade = off_tgraze + align256(h.tri_graze.size() * sizeof(int32_t));
+    size_t off_tpos = off_shade + align256(h.shade.size() * sizeof(GpuShadeRec));
+    size_t off_objs = off_tpos + align256(h.tri_pos.size() * sizeof(uint32_t));
+    size_t off_xobj = off_objs + align256(h.objs.size() * sizeof(CxObject));
+    size_t off_pobj = off_xobj + align256(h.xobj.size() * sizeof(int32_t));
+    size_t off_oleaf = off_pobj + align256(h.pos_obj.size() * sizeof(int32_t));
+    size_t off_opos = off_oleaf + align256(h.obj_leaf.size() * sizeof(uint32_t));
+    size_t total = off_opos + align256(h.obj_pos0.size() * sizeof(uint32_t));
+    hipError_t e = hipMalloc(&s->d_blob, total);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(scene)");
+    s->blob_bytes = total;
+    char* base = static_cast<char*>(s->d_blob);
+    struct { size_t off; const void* src; size_t bytes; } parts[] = {
+        {off_nodes, h.nodes.data(), h.nodes.size() * sizeof(GpuNode)},
+        {off_tris, h.tris.data(), h.tris.size() * sizeof(GpuTri)},
+        {off_np, h.node_parent.data(), h.node_parent.size() * sizeof(uint32_t)},
+        {off_st, h.stris.data(), h.stris.size() * sizeof(GpuTri)},
+        {off_sl, h.sleaf.data(), h.sleaf.size() * sizeof(uint32_t)},
+        {off_xn, h.xnodes.data(), h.xnodes.size() * sizeof(GpuQuadNode)},
+        {off_xt, h.xtris.data(), h.xtris.size() * sizeof(GpuTri)},
+        {off_aux, h.aux.data(), h.aux.size() * sizeof(GpuTriAux)},
+        {off_mats, h.mats.data(), h.mats.size() * sizeof(GpuMaterial)},
+        {off_ltri, h.light_tris.data(), h.light_tris.size() * sizeof(uint32_t)},
+        {off_lacc, h.light_accum.data(), h.light_accum.size() * sizeof(double)},
+        {off_tleaf, h.tri_leaf.data(), h.tri_leaf.size() * sizeof(uint32_t)},
+        {off_tgraze, h.tri_graze.data(), h.tri_graze.size() * sizeof(int32_t)},
+        {off_shade, h.shade.data(), h.shade.size() * sizeof(GpuShadeRec)},
+        {off_tpos, h.tri_pos.data(), h.tri_pos.size() * sizeof(uint32_t)},
+        {off_objs, h.objs.data(), h.objs.size() * sizeof(CxObject)},
+        {off_xobj, h.xobj.data(), h.xobj.size() * sizeof(int32_t)},
+        {off_pobj, h.pos_obj.data(), h.pos_obj.size() * sizeof(int32_t)},
+        {off_oleaf, h.obj_leaf.data(), h.obj_leaf.size() * sizeof(uint32_t)},
+        {off_opos, h.obj_pos0.data(), h.obj_pos0.size() * sizeof(uint32_t)},
+    };
+    for (auto& p : parts) {
+        if (p.bytes == 0) continue;
+        e = hipMemcpy(base + p.off, p.src, p.bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(s->d_blob); s->d_blob = nullptr; return hip_fail(e, "hipMemcpy(scene)"); }
+    }
+    SceneDev& d = s->dev;
+    d.nodes = reinterpret_cast<const GpuNode*>(base + off_nodes);
+    d.tris = reinterpret_cast<const GpuTri*>(base + off_tris);
+    d.node_parent = reinterpret_cast<const uint32_t*>(base + off_np);
+    d.stris = reinterpret_cast<const GpuTri*>(base + off_st);
+    d.sleaf = reinterpret_cast<const uint32_t*>(base + off_sl);
+    d.tri_leaf = reinterpret_cast<const uint32_t*>(base + off_tleaf);
+    d.tri_graze = reinterpret_cast<const int32_t*>(base + off_tgraze);
+    d.xnodes = reinterpret_cast<const GpuQuadNode*>(base + off_xn);
+    d.xtris = reinterpret_cast<const GpuTri*>(base + off_xt);
+    d.n_xnodes = (uint32_t)h.xnodes.size();
+    d.aux = reinterpret_cast<const GpuTriAux*>(base + off_aux);
+    d.mats = reinterpret_cast<const GpuMaterial*>(base + off_mats);
+    d.shade = reinterpret_cast<const GpuShadeRec*>(base + off_shade);
+    d.tri_pos = reinterpret_cast<const uint32_t*>(base + off_tpos);
+    d.light_tris = reinterpret_cast<const uint32_t*>(base + off_ltri);
+    d.light_accum = reinterpret_cast<const double*>(base + off_lacc);
+    d.light_total_area = h.light_total_area;
+    d.coord_bound = h.coord_bound;
+    d.bary_margin = h.bary_margin;
+    d.n_nodes = (uint32_t)h.nodes.size();
+    d.n_tris = (uint32_t)h.tris.size();
+    d.n_mats = (uint32_t)h.mats.size();
+    d.n_lights = s->composite ? h.n_lights : (uint32_t)h.light_tris.size();
+    d.ref_nested = h.ref_nested ? 1u : 0u;
+    const bool inst = !h.objs.empty();
+    d.objs = inst ? reinterpret_cast<const CxObject*>(base + off_objs) : nullptr;
+    d.xobj = inst ? reinterpret_cast<const int32_t*>(base + off_xobj) : nullptr;
+    d.pos_obj = inst ? reinterpret_cast<const int32_t*>(base + off_pobj) : nullptr;
+    d.obj_leaf = inst ? reinterpret_cast<const uint32_t*>(base + off_oleaf) : nullptr;
+    d.obj_pos0 = inst ? reinterpret_cast<const uint32_t*>(base + off_opos) : nullptr;
     return BDPT_OK;
 }
 
@@ -782,75 +879,8 @@ int bdpt_scene_create(bdpt_context* ctx, const double* tri_vertices, const int32
     }
     if (!err.empty()) { delete s; return fail(BDPT_ERR_INVALID_ARGUMENT, err); }
 
-    const HostScene& h = s->host;
-    // one device allocation, tables at 256-byte aligned offsets
-    size_t off_nodes = 0;
-    size_t off_tris = off_nodes + align256(h.nodes.size() * sizeof(GpuNode));
-    size_t off_np = off_tris + align256(h.tris.size() * sizeof(GpuTri));
-    size_t off_st = off_np + align256(h.node_parent.size() * sizeof(uint32_t));
-    size_t off_sl = off_st + align256(h.stris.size() * sizeof(GpuTri));
-    size_t off_xn = off_sl + align256(h.sleaf.size() * sizeof(uint32_t));
-    size_t off_xt = off_xn + align256(h.xnodes.size() * sizeof(GpuQuadNode));
-    size_t off_aux = off_xt + align256(h.xtris.size() * sizeof(GpuTri));
-    size_t off_mats = off_aux + align256(h.aux.size() * sizeof(GpuTriAux));
-    size_t off_ltri = off_mats + align256(h.mats.size() * sizeof(GpuMaterial));
-    size_t off_lacc = off_ltri + align256(h.light_tris.size() * sizeof(uint32_t));
-    size_t off_tleaf = off_lacc + align256(h.light_accum.size() * sizeof(double));
-    size_t off_tgraze = off_tleaf + align256(h.tri_leaf.size() * sizeof(uint32_t));
-    size_t off_shade = off_tgraze + align256(h.tri_graze.size() * sizeof(int32_t));
-    size_t off_tpos = off_shade + align256(h.shade.size() * sizeof(GpuShadeRec));
-    size_t total = off_tpos + align256(h.tri_pos.size() * sizeof(uint32_t));
     DeviceGuard guard(ctx->device);
-    hipError_t e = hipMalloc(&s->d_blob, total);
-    if (e != hipSuccess) { delete s; return hip_fail(e, "hipMalloc(scene)"); }
-    s->blob_bytes = total;
-    char* base = static_cast<char*>(s->d_blob);
-    struct { size_t off; const void* src; size_t bytes; } parts[] = {
-        {off_nodes, h.nodes.data(), h.nodes.size() * sizeof(GpuNode)},
-        {off_tris, h.tris.data(), h.tris.size() * sizeof(GpuTri)},
-        {off_np, h.node_parent.data(), h.node_parent.size() * sizeof(uint32_t)},
-        {off_st, h.stris.data(), h.stris.size() * sizeof(GpuTri)},
-        {off_sl, h.sleaf.data(), h.sleaf.size() * sizeof(uint32_t)},
-        {off_xn, h.xnodes.data(), h.xnodes.size() * sizeof(GpuQuadNode)},
-        {off_xt, h.xtris.data(), h.xtris.size() * sizeof(GpuTri)},
-        {off_aux, h.aux.data(), h.aux.size() * sizeof(GpuTriAux)},
-        {off_mats, h.mats.data(), h.mats.size() * sizeof(GpuMaterial)},
-        {off_ltri, h.light_tris.data(), h.light_tris.size() * sizeof(uint32_t)},
-        {off_lacc, h.light_accum.data(), h.light_accum.size() * sizeof(double)},
-        {off_tleaf, h.tri_leaf.data(), h.tri_leaf.size() * sizeof(uint32_t)},
-        {off_tgraze, h.tri_graze.data(), h.tri_graze.size() * sizeof(int32_t)},
-        {off_shade, h.shade.data(), h.shade.size() * sizeof(GpuShadeRec)},
-        {off_tpos, h.tri_pos.data(), h.tri_pos.size() * sizeof(uint32_t)},
-    };
-    for (auto& p : parts) {
-        e = hipMemcpy(base + p.off, p.src, p.bytes, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return hip_fail(e, "hipMemcpy(scene)"); }
-    }
-    SceneDev& d = s->dev;
-    d.nodes = reinterpret_cast<const GpuNode*>(base + off_nodes);
-    d.tris = reinterpret_cast<const GpuTri*>(base + off_tris);
-    d.node_parent = reinterpret_cast<const uint32_t*>(base + off_np);
-    d.stris = reinterpret_cast<const GpuTri*>(base + off_st);
-    d.sleaf = reinterpret_cast<const uint32_t*>(base + off_sl);
-    d.tri_leaf = reinterpret_cast<const uint32_t*>(base + off_tleaf);
-    d.tri_graze = reinterpret_cast<const int32_t*>(base + off_tgraze);
-    d.xnodes = reinterpret_cast<const GpuQuadNode*>(base + off_xn);
-    d.xtris = reinterpret_cast<const GpuTri*>(base + off_xt);
-    d.n_xnodes = (uint32_t)h.xnodes.size();
-    d.aux = reinterpret_cast<const GpuTriAux*>(base + off_aux);
-    d.mats = reinterpret_cast<const GpuMaterial*>(base + off_mats);
-    d.shade = reinterpret_cast<const GpuShadeRec*>(base + off_shade);
-    d.tri_pos = reinterpret_cast<const uint32_t*>(base + off_tpos);
-    d.light_tris = reinterpret_cast<const uint32_t*>(base + off_ltri);
-    d.light_accum = reinterpret_cast<const double*>(base + off_lacc);
-    d.light_total_area = h.light_total_area;
-    d.coord_bound = h.coord_bound;
-    d.bary_margin = h.bary_margin;
-    d.n_nodes = (uint32_t)h.nodes.size();
-    d.n_tris = (uint32_t)h.tris.size();
-    d.n_mats = (uint32_t)h.mats.size();
-    d.n_lights = (uint32_t)h.light_tris.size();
-    d.ref_nested = h.ref_nested ? 1u : 0u;
+    { int rc = upload_pipeline_tables(ctx, s); if (rc != BDPT_OK) { delete s; return rc; } }
     *out = s;
     return BDPT_OK;
 }
@@ -909,13 +939,13 @@ int bdpt_scene_create_composite(bdpt_context* ctx, const double* tri_vertices, c
     };
     size_t total = 0;
     for (Part& p : parts) { p.off = total; total += align256(p.bytes); }
-    hipError_t e = hipMalloc(&s->d_blob, total);
+    hipError_t e = hipMalloc(&s->d_cx_blob, total);
     if (e != hipSuccess) { delete s; return hip_fail(e, "hipMalloc(scene)"); }
-    s->blob_bytes = total;
-    char* base = static_cast<char*>(s->d_blob);
+    s->cx_blob_bytes = total;
+    char* base = static_cast<char*>(s->d_cx_blob);
     for (const Part& p : parts) {
         e = hipMemcpy(base + p.off, p.src, p.bytes, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return hip_fail(e, "hipMemcpy(scene)"); }
+        if (e != hipSuccess) { (void)hipFree(s->d_cx_blob); delete s; return hip_fail(e, "hipMemcpy(scene)"); }
     }
     CxSceneDev& d = s->cx_dev;
     d.nodes = reinterpret_cast<const GpuNode*>(base + parts[0].off);
@@ -939,6 +969,20 @@ int bdpt_scene_create_composite(bdpt_context* ctx, const double* tri_vertices, c
     d.n_media = 0;
     for (const CxObject& ob : h.objs) d.n_media += (ob.flags & kCxMedium) ? 1u : 0u;
     d.pad = 0;
+    // Instances without media or textures also get the tables of the render pipeline; everything else is rendered by
+    // the single kernel alone.
+    s->pipeline = false;
+    if (h.pipeline_ok && !std::getenv("BDPT_COMPOSITE_SINGLE_KERNEL")) {
+        try {
+            err = build_instanced_pipeline(s->cx_host, s->host);
+        } catch (const std::bad_alloc&) {
+            err = "host allocation failed while building the pipeline tables";
+        }
+        if (!err.empty()) { (void)hipFree(s->d_cx_blob); delete s; return fail(BDPT_ERR_INVALID_ARGUMENT, err); }
+        int rc = upload_pipeline_tables(ctx, s);
+        if (rc != BDPT_OK) { (void)hipFree(s->d_cx_blob); delete s; return rc; }
+        s->pipeline = true;
+    }
     *out = s;
     return BDPT_OK;
 }
@@ -948,6 +992,7 @@ int bdpt_scene_destroy(bdpt_scene* scene) {
     DeviceGuard guard(scene->ctx->device);
     (void)hipDeviceSynchronize();
     if (scene->d_blob) (void)hipFree(scene->d_blob);
+    if (scene->d_cx_blob) (void)hipFree(scene->d_cx_blob);
     delete scene;
     return BDPT_OK;
 }
@@ -961,7 +1006,7 @@ int bdpt_scene_get_info(const bdpt_scene* scene, bdpt_scene_info* out) {
         out->n_nodes = scene->cx_dev.n_nodes;
         out->max_depth = scene->cx_host.tree_depth;
         out->reserved = 0;
-        out->device_bytes = scene->blob_bytes;
+        out->device_bytes = scene->blob_bytes + scene->cx_blob_bytes;
         return BDPT_OK;
     }
     out->n_triangles = scene->dev.n_tris;
@@ -1003,7 +1048,7 @@ int bdpt_trace_closest_device(bdpt_context* ctx, const bdpt_scene* scene, const 
     if (scene->ctx != ctx) return fail(BDPT_ERR_INVALID_ARGUMENT, "scene belongs to another context");
     if (n == 0) return BDPT_OK;
     DeviceGuard guard(ctx->device);
-    if (scene->composite) {
+    if (scene->composite && !(scene->pipeline && ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene))) {
         HIP_TRY(cx_launch_trace_closest(scene->cx_dev, static_cast<const double*>(d_rays), n, static_cast<double*>(d_hits), nullptr,
                                         static_cast<hipStream_t>(stream)));
         return BDPT_OK;
@@ -1032,7 +1077,7 @@ int bdpt_trace_closest(bdpt_context* ctx, const bdpt_scene* scene, const double*
         if ((e = hipMemcpy(d_rays, rays, n * 8 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
         if (stats && (e = hipMemset(ctx->stats, 0, sizeof(unsigned long long) * kStatWords)) != hipSuccess) break;
         // counters have the reference's meaning, so a counting call walks the reference's own tree
-        if (scene->composite) {
+        if (scene->composite && (stats || !(scene->pipeline && ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene)))) {
             if ((e = cx_launch_trace_closest(scene->cx_dev, d_rays, n, d_hits, stats ? ctx->stats : nullptr, nullptr)) != hipSuccess) break;
         } else if (!stats && ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene)) {
             rc = trace_closest_pipeline(ctx, scene, d_rays, n, d_hits, nullptr);
@@ -1064,7 +1109,7 @@ int bdpt_visible(bdpt_context* ctx, const bdpt_scene* scene, const double* pairs
     int rc = BDPT_OK;
     do {
         if ((e = hipMemcpy(d_pairs, pairs, n * 6 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
-        if (scene->composite) {
+        if (scene->composite && !(scene->pipeline && ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene))) {
             if ((e = cx_launch_visible(scene->cx_dev, d_pairs, n, d_out, nullptr)) != hipSuccess) break;
         } else if (ctx->query_walker == BDPT_WALKER_PIPELINE && pipeline_can_walk(scene)) {
             rc = visible_pipeline(ctx, scene, d_pairs, n, d_out, nullptr);

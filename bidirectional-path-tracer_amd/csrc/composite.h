@@ -15,19 +15,6 @@
 
 namespace bdpt {
 
-constexpr uint32_t kCxRotate = 1u, kCxTranslate = 2u, kCxMedium = 4u;
-
-// One object of the world's list (src/objects/hittable.h:46-157, src/materials/volumes/constant_medium.h).
-struct CxObject {
-    double sin_theta, cos_theta;   // rotate_y::rotate_y, hittable.h:79-81
-    double offset[3];              // translate
-    double neg_inv_density;        // constant_medium.h:11
-    uint32_t root;                 // first record of the object's own bvh_node tree in the node table
-    uint32_t flags;                // kCx*
-    int32_t phase_material;
-    uint32_t pad;
-};
-
 // src/materials/textures/texture.h
 struct CxTexture {
     double rgb[3];
@@ -78,6 +65,9 @@ struct CxHostScene {
     std::vector<double> light_accum;
     double light_total_area = 0.0;
     uint32_t n_lights = 0;               // size of the light collection (the tables hold one dummy entry when it is empty)
+    std::vector<uint32_t> node_parent;   // parent of every record of `nodes` inside its own tree (kEndOfTree for a root)
+    std::vector<uint32_t> first_triangle, mesh_triangles;   // per object: its mesh
+    bool pipeline_ok = false;            // no medium and no texture: the scene can also run on the render pipeline
     std::vector<int32_t> world_leaves;   // leaf references of the world's tree in the reference's visiting order
     uint32_t n_world_nodes = 0;          // records [0, n_world_nodes) are the world's tree
     uint32_t tree_depth = 0;
@@ -90,6 +80,10 @@ std::string build_composite_scene(const double* tri_vertices, const int32_t* tri
                                   uint32_t n_textures, const bdpt_object* objects, uint32_t n_objects,
                                   const double* sin_theta, const double* cos_theta, const uint32_t* light_triangles,
                                   uint32_t n_lights, CxHostScene& out);
+
+// Tables of the render pipeline for a composite scene with pipeline_ok (scene_build.h: HostScene).
+struct HostScene;
+std::string build_instanced_pipeline(const CxHostScene& cx, HostScene& out);
 
 struct CxRenderLaunch {
     uint64_t seed;

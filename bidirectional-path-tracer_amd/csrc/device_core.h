@@ -354,13 +354,22 @@ BDPT_DEV void shade_bounce_at(const SceneDev& sc, uint32_t pos, V3 o, V3 d, doub
     shade_bounce<EYE, LAMBERT>(m, (int32_t)r.tri, o, d, t_hit, throughput, rng, out);
 }
 
+// (p, normal, front_face: the hit_record as the world's hit() returned it; d: the ray's direction)
+template <bool EYE, bool LAMBERT>
+BDPT_DEV void shade_surface(const ShadeMat& m, int32_t tri, V3 p, V3 normal, bool front_face, V3 d, V3 throughput, Rng& rng, Bounce& out);
+
 template <bool EYE, bool LAMBERT>
 BDPT_DEV void shade_bounce(const ShadeMat& m, int32_t tri, V3 o, V3 d, double t_hit, V3 throughput, Rng& rng, Bounce& out) {
-    const int32_t mat_id = m.id;
     V3 p = add(o, scl(t_hit, d));                                         // ray.h:21-23
     V3 outward = m.normal;
     bool front_face = dot(d, outward) < 0;                                // hittable.h:20-26
     V3 normal = front_face ? outward : neg(outward);
+    shade_surface<EYE, LAMBERT>(m, tri, p, normal, front_face, d, throughput, rng, out);
+}
+
+template <bool EYE, bool LAMBERT>
+BDPT_DEV void shade_surface(const ShadeMat& m, int32_t tri, V3 p, V3 normal, bool front_face, V3 d, V3 throughput, Rng& rng, Bounce& out) {
+    const int32_t mat_id = m.id;
 
     out.keep = (m.type == 0 || m.type == 3);
     out.vx.p = p; out.vx.n = normal; out.vx.T = throughput;

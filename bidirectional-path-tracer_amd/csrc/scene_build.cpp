@@ -308,6 +308,85 @@ struct QuadCollapse {
     }
 };
 
+// Closest-hit hierarchy over the entries of `out.stris` (referenced by their position there).  world_box[p]: the
+// box of entry p where rays meet it; own_box[p]: the box of its triangle in the coordinates its test runs in (the two
+// differ for a triangle of an instanced mesh).
+static void build_traversal_hierarchy(HostScene& out, const std::vector<Box3>& world_box, const std::vector<Box3>& own_box) {
+    const uint32_t n_tri = (uint32_t)out.tris.size();
+    {
+        SahBuilder sb;
+        if (const char* v = std::getenv("BDPT_SAH_MIN_LEAF")) {      // a leaf reference has room for 1..4 triangles
+            const int m = std::atoi(v);
+            sb.min_leaf = (size_t)(m < 1 ? 1 : (m > 4 ? 4 : m));
+        }
+        if (const char* v = std::getenv("BDPT_SAH_BOX_COST")) sb.box_cost = std::atof(v);
+        sb.refs.resize(out.stris.size());
+        for (size_t p = 0; p < out.stris.size(); p++) {
+            SahRef& r = sb.refs[p];
+            r.pos = (uint32_t)p;
+            for (int k = 0; k < 3; k++) {
+                // the triangle's exact box, padded on every axis: at least the reference's own padding of
+                // thin boxes (aabb.h:81-88), and well above the rounding of an accepted hit point
+                const double pad = std::fmax(5e-5, 1e-9 * std::fmax(std::fabs(world_box[p].lo[k]), std::fabs(world_box[p].hi[k])));
+                r.lo[k] = world_box[p].lo[k] - pad;
+                r.hi[k] = world_box[p].hi[k] + pad;
+                r.c[k] = 0.5 * (r.lo[k] + r.hi[k]);
+            }
+        }
+        sb.nodes.reserve(out.stris.size());
+        sb.leaf_order.reserve(out.stris.size());
+        int32_t root = sb.build(0, sb.refs.size(), 1);
+        if (root < 0) {                        // one leaf only: wrap it so that record 0 exists
+            SahBinNode w{};
+            double lo[3], hi[3];
+            sb.bounds(0, sb.refs.size(), lo, hi);
+            for (int k = 0; k < 3; k++) {
+                w.lo0[k] = round_down(lo[k]); w.hi0[k] = round_up(hi[k]);
+                w.lo1[k] = std::numeric_limits<float>::infinity(); w.hi1[k] = -std::numeric_limits<float>::infinity();
+            }
+            w.child0 = root;
+            w.child1 = kQuadEmpty;
+            sb.nodes.push_back(w);
+        }
+        QuadCollapse qc(sb.nodes);
+        qc.collapse(0, 0);
+        hoist_top_levels<4>(qc.out, kLdsTopQuadNodes, [](GpuQuadNode& q) { return &q.child[0]; });
+        out.xnodes.swap(qc.out);
+        out.sah_stack = qc.stack_need;
+        out.coord_bound = 0.0;
+        for (const SahRef& r : sb.refs)
+            for (int k = 0; k < 3; k++) out.coord_bound = std::fmax(out.coord_bound, std::fmax(std::fabs(r.lo[k]), std::fabs(r.hi[k])));
+        for (const Box3& bx : own_box)       // (a mesh's own coordinates, where its triangle tests run)
+            for (int k = 0; k < 3; k++) out.coord_bound = std::fmax(out.coord_bound, std::fmax(std::fabs(bx.lo[k]), std::fabs(bx.hi[k])));
+        out.coord_bound = (double)round_up(out.coord_bound * 1.0000002);     // covers the outward FP32 rounding of the boxes
+        // Hits the traversal kernels re-check against the reference's own tree (wavefront.hip, "exact ties"): a hit
+        // within bary_margin of the triangle's outline, or by a ray within 1e-4 rad of the triangle's plane
+        // (|det| = |d . (e1 x e2)| below 1e-4 |d| |e1 x e2|; the threshold without the |d| is kept per triangle: the
+        // high 32 bits of that double, in the otherwise unused material field).  The margin argument needs a hit inside the outline
+        // to be at least ~64 ulp of the coordinates inside the triangle's box on every axis the box is not thin
+        // (< 1e-4, where the reference pads) on: bary_margin * 1e-4 >= 64 ulp(4 * coord_bound).  A triangle whose
+        // box is thin on two axes has no such axis pair and is always re-checked (threshold +infinity).
+        out.bary_margin = std::fmax(1e-6, 64.0 * 0x1p-52 * 4.0 * out.coord_bound / 1e-4);
+        out.xtris.resize(sb.leaf_order.size());
+        out.tri_graze.assign(n_tri, 0);
+        for (size_t k = 0; k < sb.leaf_order.size(); k++) {
+            GpuTri t = out.stris[sb.leaf_order[k]];
+            const uint32_t id = (uint32_t)t.pad;
+            t.pad = (int32_t)sb.leaf_order[k];
+            int thin_axes = 0;
+            for (int a = 0; a < 3; a++) thin_axes += (own_box[sb.leaf_order[k]].hi[a] - own_box[sb.leaf_order[k]].lo[a] < 1e-4) ? 1 : 0;
+            double graze = 1e-4 * 2.0 * out.aux[id].area;                // |e1 x e2| = 2 area
+            if (thin_axes >= 2 || !(graze == graze)) graze = std::numeric_limits<double>::infinity();
+            uint64_t bits;
+            std::memcpy(&bits, &graze, sizeof bits);
+            t.material = (int32_t)(uint32_t)(bits >> 32) + 1;            // high word, rounded up
+            out.tri_graze[id] = t.material;
+            out.xtris[k] = t;
+        }
+    }
+
+}
+
 }  // namespace
 
 std::string build_host_scene(const double* tv, const int32_t* tri_material, uint32_t n_tri,
@@ -453,74 +532,9 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
 
     // closest-hit hierarchy over the same triangles (referenced by their position in `stris`)
     {
-        SahBuilder sb;
-        if (const char* v = std::getenv("BDPT_SAH_MIN_LEAF")) {      // a leaf reference has room for 1..4 triangles
-            const int m = std::atoi(v);
-            sb.min_leaf = (size_t)(m < 1 ? 1 : (m > 4 ? 4 : m));
-        }
-        if (const char* v = std::getenv("BDPT_SAH_BOX_COST")) sb.box_cost = std::atof(v);
-        sb.refs.resize(out.stris.size());
-        for (size_t p = 0; p < out.stris.size(); p++) {
-            const uint32_t id = (uint32_t)out.stris[p].pad;
-            SahRef& r = sb.refs[p];
-            r.pos = (uint32_t)p;
-            for (int k = 0; k < 3; k++) {
-                // the triangle's exact box, padded on every axis: at least the reference's own padding of
-                // thin boxes (aabb.h:81-88), and well above the rounding of an accepted hit point
-                const double pad = std::fmax(5e-5, 1e-9 * std::fmax(std::fabs(btris[id].box.lo[k]), std::fabs(btris[id].box.hi[k])));
-                r.lo[k] = btris[id].box.lo[k] - pad;
-                r.hi[k] = btris[id].box.hi[k] + pad;
-                r.c[k] = 0.5 * (r.lo[k] + r.hi[k]);
-            }
-        }
-        sb.nodes.reserve(out.stris.size());
-        sb.leaf_order.reserve(out.stris.size());
-        int32_t root = sb.build(0, sb.refs.size(), 1);
-        if (root < 0) {                        // one leaf only: wrap it so that record 0 exists
-            SahBinNode w{};
-            double lo[3], hi[3];
-            sb.bounds(0, sb.refs.size(), lo, hi);
-            for (int k = 0; k < 3; k++) {
-                w.lo0[k] = round_down(lo[k]); w.hi0[k] = round_up(hi[k]);
-                w.lo1[k] = std::numeric_limits<float>::infinity(); w.hi1[k] = -std::numeric_limits<float>::infinity();
-            }
-            w.child0 = root;
-            w.child1 = kQuadEmpty;
-            sb.nodes.push_back(w);
-        }
-        QuadCollapse qc(sb.nodes);
-        qc.collapse(0, 0);
-        hoist_top_levels<4>(qc.out, kLdsTopQuadNodes, [](GpuQuadNode& q) { return &q.child[0]; });
-        out.xnodes.swap(qc.out);
-        out.sah_stack = qc.stack_need;
-        out.coord_bound = 0.0;
-        for (const SahRef& r : sb.refs)
-            for (int k = 0; k < 3; k++) out.coord_bound = std::fmax(out.coord_bound, std::fmax(std::fabs(r.lo[k]), std::fabs(r.hi[k])));
-        out.coord_bound = (double)round_up(out.coord_bound * 1.0000002);     // covers the outward FP32 rounding of the boxes
-        // Hits the traversal kernels re-check against the reference's own tree (wavefront.hip, "exact ties"): a hit
-        // within bary_margin of the triangle's outline, or by a ray within 1e-4 rad of the triangle's plane
-        // (|det| = |d . (e1 x e2)| below 1e-4 |d| |e1 x e2|; the threshold without the |d| is kept per triangle: the
-        // high 32 bits of that double, in the otherwise unused material field).  The margin argument needs a hit inside the outline
-        // to be at least ~64 ulp of the coordinates inside the triangle's box on every axis the box is not thin
-        // (< 1e-4, where the reference pads) on: bary_margin * 1e-4 >= 64 ulp(4 * coord_bound).  A triangle whose
-        // box is thin on two axes has no such axis pair and is always re-checked (threshold +infinity).
-        out.bary_margin = std::fmax(1e-6, 64.0 * 0x1p-52 * 4.0 * out.coord_bound / 1e-4);
-        out.xtris.resize(sb.leaf_order.size());
-        out.tri_graze.assign(n_tri, 0);
-        for (size_t k = 0; k < sb.leaf_order.size(); k++) {
-            GpuTri t = out.stris[sb.leaf_order[k]];
-            const uint32_t id = (uint32_t)t.pad;
-            t.pad = (int32_t)sb.leaf_order[k];
-            int thin_axes = 0;
-            for (int a = 0; a < 3; a++) thin_axes += (btris[id].box.hi[a] - btris[id].box.lo[a] < 1e-4) ? 1 : 0;
-            double graze = 1e-4 * 2.0 * out.aux[id].area;                // |e1 x e2| = 2 area
-            if (thin_axes >= 2 || !(graze == graze)) graze = std::numeric_limits<double>::infinity();
-            uint64_t bits;
-            std::memcpy(&bits, &graze, sizeof bits);
-            t.material = (int32_t)(uint32_t)(bits >> 32) + 1;            // high word, rounded up
-            out.tri_graze[id] = t.material;
-            out.xtris[k] = t;
-        }
+        std::vector<Box3> boxes(out.stris.size());
+        for (size_t p = 0; p < out.stris.size(); p++) boxes[p] = btris[(uint32_t)out.stris[p].pad].box;
+        build_traversal_hierarchy(out, boxes, boxes);
     }
 
     // the light collection handed to camera::render: `lights`, or the whole world when it is empty (main.cpp:67)
@@ -575,9 +589,12 @@ void precompute_triangle(const double* v0, int32_t material, GpuTri& t, GpuTriAu
 // One bvh_node tree in pre-order -> threaded records appended to `out`.  item_ref[i]: the leaf reference of list
 // entry i (triangle id, or -(object + 2)).  `leaves` receives the references in visiting order.
 void append_threaded(const std::vector<BuildNode>& bn, const std::vector<int32_t>& item_ref, std::vector<GpuNode>& out,
-                     uint32_t& tree_depth, std::vector<int32_t>* leaves) {
+                     uint32_t& tree_depth, std::vector<int32_t>* leaves, std::vector<uint32_t>& parents) {
     const uint32_t base = (uint32_t)out.size();
     const uint32_t n = (uint32_t)bn.size();
+    parents.resize(base + n, kEndOfTree);
+    for (uint32_t i = 0; i < n; i++)
+        if (bn[i].left >= 0) { parents[base + (uint32_t)bn[i].left] = base + i; parents[base + (uint32_t)bn[i].right] = base + i; }
     std::vector<uint32_t> subtree_end(n), depth(n, 1);
     for (int64_t i = (int64_t)n - 1; i >= 0; i--) subtree_end[i] = (bn[i].left >= 0) ? subtree_end[bn[i].right] : (uint32_t)i + 1;
     for (uint32_t i = 0; i < n; i++) {
@@ -802,7 +819,7 @@ std::string build_composite_scene(const double* tv, const int32_t* tri_material,
     wb.build(0, items.size());
 
     out.tree_depth = 1;
-    append_threaded(wb.nodes, item_ref, out.nodes, out.tree_depth, &out.world_leaves);
+    append_threaded(wb.nodes, item_ref, out.nodes, out.tree_depth, &out.world_leaves, out.node_parent);
     out.n_world_nodes = (uint32_t)out.nodes.size();
     for (uint32_t k = 0; k < n_obj; k++) {
         if (mesh_of[k] != (int32_t)k) continue;
@@ -810,7 +827,7 @@ std::string build_composite_scene(const double* tv, const int32_t* tri_material,
         for (uint32_t i = 0; i < objects[k].n_triangles; i++) refs[i] = (int32_t)(objects[k].first_triangle + i);
         out.objs[k].root = (uint32_t)out.nodes.size();
         uint32_t d = 1;
-        append_threaded(obj_nodes[k], refs, out.nodes, d, nullptr);
+        append_threaded(obj_nodes[k], refs, out.nodes, d, nullptr, out.node_parent);
     }
     for (uint32_t k = 0; k < n_obj; k++) out.objs[k].root = out.objs[mesh_of[k]].root;
 
@@ -833,6 +850,146 @@ std::string build_composite_scene(const double* tv, const int32_t* tri_material,
     out.light_total_area = accum;
     out.n_lights = (uint32_t)out.light_tris.size();
     if (out.light_tris.empty()) { out.light_tris.push_back(0); out.light_accum.push_back(0.0); out.light_total_area = 0.0; }
+    out.first_triangle.resize(n_obj);
+    out.mesh_triangles.resize(n_obj);
+    for (uint32_t k = 0; k < n_obj; k++) { out.first_triangle[k] = objects[k].first_triangle; out.mesh_triangles[k] = objects[k].n_triangles; }
+    out.pipeline_ok = true;                                   // instances only, solid colours only: see composite.h
+    for (const CxObject& ob : out.objs) if (ob.flags & kCxMedium) out.pipeline_ok = false;
+    for (const GpuMaterial& m : out.mats) if (m.pad > 0) out.pipeline_ok = false;
+    return std::string();
+}
+
+// Tables of the render pipeline (SceneDev) for a composite scene that holds instances only.  The leaf order is the
+// reference's visiting order over the two-level structure: the leaves of the world's tree left to right, an object
+// standing for the triangles of its mesh in the order of the mesh's own tree.
+std::string build_instanced_pipeline(const CxHostScene& cx, HostScene& out) {
+    out = HostScene();
+    const uint32_t n_tri = (uint32_t)cx.tris.size();
+    const uint32_t n_obj = (uint32_t)cx.objs.size();
+    out.nodes = cx.nodes;
+    out.node_parent = cx.node_parent;
+    out.tris = cx.tris;
+    out.aux = cx.aux;
+    out.mats = cx.mats;
+    for (GpuMaterial& m : out.mats) m.pad = 0;
+    out.light_tris = cx.light_tris;
+    out.light_accum = cx.light_accum;
+    out.light_total_area = cx.light_total_area;
+    out.n_lights = cx.n_lights;
+    out.tree_depth = cx.tree_depth;
+    out.objs = cx.objs;
+    for (uint32_t i = 0; i < n_tri; i++) if (out.mats[out.tris[i].material].type == BDPT_LAMBERTIAN) out.has_lambertian = true;
+
+    // every box of a tree contains the boxes below it (what reference_reaches relies on), checked tree by tree
+    out.ref_nested = true;
+    for (uint32_t i = 0; i < out.nodes.size(); i++) {
+        const uint32_t p = out.node_parent[i];
+        if (p == kEndOfTree) continue;
+        for (int k = 0; k < 3; k++)
+            if (!(out.nodes[p].lo[k] <= out.nodes[i].lo[k] && out.nodes[i].hi[k] <= out.nodes[p].hi[k])) out.ref_nested = false;
+    }
+    const uint32_t nested_bit = out.ref_nested ? 0x80000000u : 0u;
+
+    // leaves of one tree of the table, in visiting order: (triangle or object reference, node)
+    auto leaves_of = [&](uint32_t first, uint32_t count, std::vector<std::pair<int32_t, uint32_t>>& dst) {
+        for (uint32_t i = first; i < first + count; i++) {
+            const GpuNode& g = out.nodes[i];
+            if (g.tri0 == -1) continue;
+            dst.push_back({g.tri0, i});
+            if (g.tri1 != g.tri0) dst.push_back({g.tri1, i});
+        }
+    };
+    // node count of every mesh tree: the trees follow each other in the table in the order of their roots
+    std::vector<uint32_t> roots;
+    for (uint32_t k = 0; k < n_obj; k++) roots.push_back(cx.objs[k].root);
+    std::sort(roots.begin(), roots.end());
+    roots.erase(std::unique(roots.begin(), roots.end()), roots.end());
+    auto tree_size = [&](uint32_t root) {
+        auto it = std::upper_bound(roots.begin(), roots.end(), root);
+        const uint32_t end = (it == roots.end()) ? (uint32_t)out.nodes.size() : *it;
+        return end - root;
+    };
+
+    out.tri_pos.assign(n_tri, 0);
+    out.tri_leaf.assign(n_tri, 0);
+    out.obj_leaf.assign(n_obj, 0);
+    out.obj_pos0.assign(n_obj, 0);
+    std::vector<Box3> world_box, own_box;
+    std::vector<std::pair<int32_t, uint32_t>> world;
+    leaves_of(0, cx.n_world_nodes, world);
+    auto tri_box = [&](uint32_t id, const CxObject* ob, Box3& wbox, Box3& obox) {
+        const GpuTri& t = out.tris[id];
+        double v[3][3];
+        for (int k = 0; k < 3; k++) { v[0][k] = t.v0[k]; v[1][k] = t.v0[k] + t.e1[k]; v[2][k] = t.v0[k] + t.e2[k]; }
+        for (int k = 0; k < 3; k++) {
+            obox.lo[k] = std::fmin(v[0][k], std::fmin(v[1][k], v[2][k]));
+            obox.hi[k] = std::fmax(v[0][k], std::fmax(v[1][k], v[2][k]));
+        }
+        if (ob) {                                  // where the mesh's triangle stands in the world (hittable.h:135-139,63)
+            for (int q = 0; q < 3; q++) {
+                double x = v[q][0], y = v[q][1], z = v[q][2];
+                if (ob->flags & kCxRotate) {
+                    const double nx = ob->cos_theta * x + ob->sin_theta * z, nz = -ob->sin_theta * x + ob->cos_theta * z;
+                    x = nx; z = nz;
+                }
+                if (ob->flags & kCxTranslate) { x += ob->offset[0]; y += ob->offset[1]; z += ob->offset[2]; }
+                v[q][0] = x; v[q][1] = y; v[q][2] = z;
+            }
+        }
+        for (int k = 0; k < 3; k++) {
+            wbox.lo[k] = std::fmin(v[0][k], std::fmin(v[1][k], v[2][k]));
+            wbox.hi[k] = std::fmax(v[0][k], std::fmax(v[1][k], v[2][k]));
+        }
+    };
+    auto push_entry = [&](uint32_t id, int32_t obj, uint32_t node) {
+        GpuTri t = out.tris[id];
+        t.pad = (int32_t)id;
+        out.stris.push_back(t);
+        out.sleaf.push_back(node | nested_bit);
+        out.pos_obj.push_back(obj);
+        Box3 wbox, obox;
+        tri_box(id, obj >= 0 ? &cx.objs[obj] : nullptr, wbox, obox);
+        world_box.push_back(wbox);
+        own_box.push_back(obox);
+    };
+    std::vector<char> seen(n_obj, 0);
+    for (const auto& leaf : world) {
+        if (leaf.first >= 0) {
+            const uint32_t id = (uint32_t)leaf.first;
+            out.tri_pos[id] = (uint32_t)out.stris.size();
+            out.tri_leaf[id] = leaf.second;
+            push_entry(id, -1, leaf.second);
+            continue;
+        }
+        const uint32_t k = (uint32_t)(-(leaf.first + 2));
+        if (seen[k]) continue;                     // (a node over one entry lists it twice)
+        seen[k] = 1;
+        out.obj_leaf[k] = leaf.second | nested_bit;
+        out.obj_pos0[k] = (uint32_t)out.stris.size();
+        std::vector<std::pair<int32_t, uint32_t>> mesh;
+        leaves_of(cx.objs[k].root, tree_size(cx.objs[k].root), mesh);
+        uint32_t rank = 0;
+        for (const auto& ml : mesh) {
+            const uint32_t id = (uint32_t)ml.first;
+            out.tri_pos[id] = rank++;              // (the same for every object that shares the mesh)
+            out.tri_leaf[id] = ml.second;
+            push_entry(id, (int32_t)k, ml.second);
+        }
+    }
+    if (out.stris.size() >= (1u << 29)) return "too many triangles once the instances are counted";
+    out.shade.resize(out.stris.size());
+    for (size_t p = 0; p < out.stris.size(); p++) {
+        const uint32_t id = (uint32_t)out.stris[p].pad;
+        const GpuMaterial& m = out.mats[out.tris[id].material];
+        GpuShadeRec& r = out.shade[p];
+        for (int c = 0; c < 3; c++) { r.normal[c] = out.aux[id].normal[c]; r.rgb[c] = m.rgb[c]; }
+        r.param = m.type == 1 ? m.fuzz : m.ior;
+        r.tri = id;
+        r.mat = (uint32_t)out.tris[id].material | ((uint32_t)m.type << 30);
+    }
+    build_traversal_hierarchy(out, world_box, own_box);
+    out.xobj.resize(out.xtris.size());
+    for (size_t k = 0; k < out.xtris.size(); k++) out.xobj[k] = out.pos_obj[(uint32_t)out.xtris[k].pad];
     return std::string();
 }
 

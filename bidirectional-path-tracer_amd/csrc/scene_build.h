@@ -35,6 +35,11 @@ struct HostScene {
     std::vector<double> light_accum;
     double light_total_area = 0.0;
     std::vector<uint32_t> dfs_leaves;    // triangle ids in the reference's leaf visiting order
+    uint32_t n_lights = 0;
+    // scenes with instances (see SceneDev): empty otherwise
+    std::vector<CxObject> objs;
+    std::vector<int32_t> xobj, pos_obj;
+    std::vector<uint32_t> obj_leaf, obj_pos0;
     uint32_t tree_depth = 0;
 };
 

@@ -67,6 +67,7 @@ struct WfLaunchCfg {
     int persistent_blocks;    // grid of the persistent traversal kernels
     int stream_blocks;        // grid of the grid-stride kernels
     bool lds_scene;
+    bool instanced;       // the scene holds instances: traversal and shading kernels with the ray transform in front of the triangle test
     uint32_t conn_blocks; // workgroups of k_conn_gen (each may leave up to kConnSlackPerBlock unused entries in the shadow queue)
     bool own_test;        // k_conn_gen tests the light vertex's own triangle (from tables in LDS) and keeps the pairs' contributions
     size_t lds_bytes;

@@ -5,6 +5,7 @@
 // they finish, so lanes whose ray ended early do not idle until the slowest ray of the wave is done.
 #include <hip/hip_runtime.h>
 
+#include "composite_core.h"
 #include "device_core.h"
 #include "wavefront.h"
 
@@ -388,6 +389,21 @@ struct RefTree {
 struct GlobalRefTree {
     BDPT_DEV bool reaches(const SceneDev& sc, uint32_t node_and_nested, V3 o, V3 d, double max_t) const { return reference_reaches(sc, node_and_nested, o, d, max_t); }
 };
+// Scenes with instances: the chain of boxes above an entry of `stris` runs through the mesh's own tree with the ray as
+// the mesh sees it (translate::hit / rotate_y::hit hand the interval on unchanged, hittable.h:54-66,110-148) and then
+// through the world's tree, from the node that holds the object, with the ray itself.
+__device__ __attribute__((noinline)) bool instanced_reaches(const SceneDev& sc, uint32_t pos, V3 o, V3 d, double max_t) {
+    const uint32_t leaf = sc.sleaf[pos];
+    const int32_t ob = sc.pos_obj[pos];
+    if (ob < 0) return reference_reaches(sc, leaf, o, d, max_t);
+    V3 oo = o, od = d;
+    cx_to_object(sc.objs[ob], oo, od);
+    if (!reference_reaches(sc, leaf, oo, od, max_t)) return false;
+    return reference_reaches(sc, sc.obj_leaf[ob], o, d, max_t);
+}
+struct InstancedRefTree {
+    BDPT_DEV bool reaches(const SceneDev& sc, uint32_t pos, V3 o, V3 d, double max_t) const { return instanced_reaches(sc, pos, o, d, max_t); }
+};
 BDPT_DEV size_t ref_tree_lds_bytes(uint32_t n_nodes) { return (size_t)n_nodes * (sizeof(GpuNode) + sizeof(uint32_t)); }
 // all threads of the workgroup; `dst` 16-byte aligned
 BDPT_DEV RefTree stage_ref_tree(const SceneDev& sc, unsigned char* dst) {
@@ -407,7 +423,10 @@ BDPT_DEV RefTree stage_ref_tree(const SceneDev& sc, unsigned char* dst) {
 // every time.  Lanes that reach a leaf wait until `leaf_threshold` lanes of the wave have one (or no lane
 // has an interior record left).  SHADOW: rays come from the shadow queue, the walk stops at the first
 // accepted triangle and a clear ray sets its pair's visibility bit.
-template <bool SHADOW, bool STATS, class Mem, class Ref>
+// INSTANCED: an entry of the triangle table may belong to an object; its test then takes the ray as the object's mesh
+// sees it (the reference's translate::hit / rotate_y::hit in front of triangle::hit), everything else is unchanged -
+// the ray parameter t is the same number in both coordinate systems.
+template <bool SHADOW, bool STATS, bool INSTANCED, class Mem, class Ref>
 BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, uint32_t count,
                              uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk,
                              const int kLeafThreshold, const int kLeafInner, const double coord_bound, double* lds_stack, const int kLdsStack,
@@ -549,11 +568,16 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
           for (;;) {
             if (has && leaf_left > 0 && !done) {
                 const GpuTri tr = mem.stri(leaf_next);
+                V3 to = o, td = d;
+                if (INSTANCED) {
+                    const int32_t ob = sc.xobj[leaf_next];
+                    if (ob >= 0) cx_to_object(sc.objs[ob], to, td);
+                }
                 leaf_next++;
                 leaf_left--;
                 double t, u, v, det;
                 // triangle.h:63: accepted when tmin <= t <= closest (inclusive)
-                const bool cand = tri_candidate(tr, o, d, 0.001, t, u, v, det);
+                const bool cand = tri_candidate(tr, to, td, 0.001, t, u, v, det);
                 const bool inside = cand && t <= closest;
                 if (STATS) { n_tri++; if (inside) n_tri_hits++; }
                 if (SHADOW) {
@@ -563,7 +587,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                         // (the far end point's own surface, t = max_t up to rounding: most unoccluded pairs) or a
                         // grazing one counts only if the reference's own boxes let it through.
                         const bool check = nearly_equal(t, closest) || grazes(tr, u, v, t, det, gbits);
-                        if (!check || ref.reaches(sc, sc.sleaf[tr.pad], o, d, closest)) { h.tri = tr.pad; done = true; leaf_left = 0; }
+                        if (!check || ref.reaches(sc, INSTANCED ? (uint32_t)tr.pad : sc.sleaf[tr.pad], o, d, closest)) { h.tri = tr.pad; done = true; leaf_left = 0; }
                     }
                 } else {
                     // (the walk goes on after an exact tie: rare, and the loop keeps its shape - no branch here)
@@ -654,7 +678,7 @@ BDPT_DEV void stage_tree(const NodeT* nodes, uint32_t n_nodes, const GpuTri* tri
     __syncthreads();
 }
 
-template <bool SHADOW, bool STATS, bool LDS_SCENE>
+template <bool SHADOW, bool STATS, bool LDS_SCENE, bool INSTANCED = false>
 __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
                                                     const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                     unsigned long long* stats, int refill_threshold, uint32_t chunk,
@@ -692,18 +716,23 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
             // (the copy of the reference's tree lies behind the stack part; only visibility rays consult it)
             if (SHADOW) {
                 const RefTree ref = stage_ref_tree(sc, smem + scene_lds_bytes + (size_t)(lds_stack + 1) * kBlock * sizeof(double));
-                traverse_queue<SHADOW, STATS>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
+                traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
                 return;
             }
             const GlobalRefTree ref;
-            traverse_queue<SHADOW, STATS>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
+            traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
         } else {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
             stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
             TopLdsMem<GpuQuadNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
+            if (INSTANCED) {
+                const InstancedRefTree ref;
+                traverse_queue<SHADOW, STATS, true>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
+                return;
+            }
             const GlobalRefTree ref;
-            traverse_queue<SHADOW, STATS>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
+            traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
         }
     }
 }
@@ -720,8 +749,35 @@ __device__ __attribute__((noinline)) int32_t redo_closest(const SceneDev& sc, V3
     return h.tri;
 }
 
+// The same for a scene with instances: the walk over the two-level table; returns the POSITION of the hit entry in
+// the leaf order (or -1) and which object it belongs to.
+__device__ __attribute__((noinline)) int32_t redo_closest_instanced(const SceneDev& sc, V3 o, V3 d, double tmin, double tmax, CxHit& h) {
+    Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Rng unused;
+    unused.key = 0; unused.counter = 0;            // (only a medium draws, and scenes with media do not run here)
+    h.tri = -1; h.obj = -1; h.t = 0; h.u = 0; h.v = 0;
+    if (!cx_walk<kStatsOff>(sc, o, d, tmin, tmax, h, c, unused)) return -1;
+    return (int32_t)((h.obj >= 0 ? sc.obj_pos0[h.obj] : 0u) + sc.tri_pos[h.tri]);
+}
+// hit_record of an entry of the leaf order that belongs to an object: position and normal as translate::hit /
+// rotate_y::hit return them (hittable.h:63,135-145)
+BDPT_DEV void instanced_surface(const SceneDev& sc, int32_t ob, V3 outward, V3 o, V3 d, double t_hit, V3& p, V3& normal, bool& front_face) {
+    const CxObject obj = sc.objs[ob];
+    V3 oo = o, od = d;
+    cx_to_object(obj, oo, od);
+    p = add(oo, scl(t_hit, od));
+    front_face = dot(od, outward) < 0;
+    normal = front_face ? outward : neg(outward);
+    if (obj.flags & kCxRotate) {
+        const double c = obj.cos_theta, sn = obj.sin_theta;
+        p = mk((c * p.x) + (sn * p.z), p.y, (-sn * p.x) + (c * p.z));
+        normal = mk((c * normal.x) + (sn * normal.z), normal.y, (-sn * normal.x) + (c * normal.z));
+    }
+    if (obj.flags & kCxTranslate) p = add(p, ld3(obj.offset));
+}
+
 // ------------------------------------------------------------------ shading of one bounce
-template <bool EYE, bool STATS, bool LAMBERT>
+template <bool EYE, bool STATS, bool LAMBERT, bool INSTANCED = false>
 __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
                                                   const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
                                                   uint32_t* count_out, int last_bounce, int store_vertices, unsigned long long* stats) {
@@ -747,9 +803,16 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             int32_t pos = wb.hit_tri[slot];           // position of the hit triangle in the reference's leaf order
             double t_hit = 0.0;
             if (pos == kHitRedo) {
-                const int32_t tri = redo_closest(sc, mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]),
-                                                 mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]), kInf, t_hit);
-                pos = tri < 0 ? -1 : (int32_t)sc.tri_pos[tri];
+                if (INSTANCED) {
+                    CxHit rh;
+                    pos = redo_closest_instanced(sc, mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]),
+                                                 mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]), 0.001, kInf, rh);
+                    t_hit = rh.t;
+                } else {
+                    const int32_t tri = redo_closest(sc, mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]),
+                                                     mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]), kInf, t_hit);
+                    pos = tri < 0 ? -1 : (int32_t)sc.tri_pos[tri];
+                }
             } else if (pos >= 0) t_hit = wb.hit[slot];
             V3 T = mk(wb.thr[slot], wb.thr[ns + slot], wb.thr[2 * ns + slot]);
             if (pos < 0) {
@@ -764,6 +827,17 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             const uint32_t ctr0 = wb.ctr[slot];
             Rng rng = slot_rng(cam, b, slot, ctr0);
             Bounce bo;
+            const int32_t ob = INSTANCED ? sc.pos_obj[pos] : -1;
+            if (INSTANCED && ob >= 0) {
+                const GpuShadeRec r = sc.shade[pos];
+                ShadeMat m;
+                m.normal = ld3(r.normal); m.rgb = ld3(r.rgb); m.fuzz = r.param; m.ior = r.param;
+                m.type = (int32_t)(r.mat >> 30); m.id = (int32_t)(r.mat & kVtxMatMask);
+                V3 p, normal;
+                bool front_face;
+                instanced_surface(sc, ob, m.normal, o, d, t_hit, p, normal, front_face);
+                shade_surface<EYE, LAMBERT>(m, (int32_t)r.tri, p, normal, front_face, d, T, rng, bo);
+            } else
             shade_bounce_at<EYE, LAMBERT>(sc, (uint32_t)pos, o, d, t_hit, T, rng, bo);
             // state that a bounce leaves as it was is not written again (a specular bounce keeps no vertex, a
             // dielectric one leaves the throughput alone: x * 1.0 is x)
@@ -1237,6 +1311,7 @@ __global__ __launch_bounds__(kBlock) void k_rays_in(const double* rays, uint32_t
 // hit_record of the closest hit (hittable.h:10-27): the traversal kernel reports the triangle and t; u, v are the
 // same triangle's test evaluated once more (identical arithmetic, identical bits).  The traversal kernel's lower
 // bound is the 0.001 of trace_path (camera.h:336); a ray with another tmin takes the reference's own walk here.
+template <bool INSTANCED>
 __global__ __launch_bounds__(kBlock) void k_hits_out(SceneDev sc, const double* rays, uint32_t n, WfBuffers wb, double* hits) {
     Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
@@ -1244,6 +1319,33 @@ __global__ __launch_bounds__(kBlock) void k_hits_out(SceneDev sc, const double* 
         const V3 o = mk(in[0], in[1], in[2]), d = mk(in[3], in[4], in[5]);
         HitLite h;
         h.tri = -1; h.t = 0; h.u = 0; h.v = 0;
+        if (INSTANCED) {
+            int32_t pos = (in[6] == 0.001) ? wb.hit_tri[k] : kHitRedo;
+            CxHit ch;
+            ch.tri = -1; ch.obj = -1; ch.t = 0; ch.u = 0; ch.v = 0;
+            if (pos == kHitRedo) {
+                pos = redo_closest_instanced(sc, o, d, in[6], in[7], ch);
+            } else if (pos >= 0) {
+                ch.tri = sc.stris[pos].pad;
+                ch.obj = sc.pos_obj[pos];
+                V3 oo = o, od = d;
+                if (ch.obj >= 0) cx_to_object(sc.objs[ch.obj], oo, od);
+                double t, u, v;
+                if (tri_test(sc.tris[ch.tri], oo, od, 0.001, kInf, t, u, v)) { ch.t = t; ch.u = u; ch.v = v; }
+            }
+            double* out = hits + 11 * (uint64_t)k;
+            if (pos < 0) {
+                out[0] = -1.0;
+#pragma unroll
+                for (int q = 1; q < 11; q++) out[q] = 0.0;
+            } else {
+                CxSurf sf;
+                cx_surface(sc, o, d, ch, sf);
+                out[0] = (double)ch.tri; out[1] = ch.t; out[2] = ch.u; out[3] = ch.v; out[4] = sf.front ? 1.0 : 0.0;
+                out[5] = sf.p.x; out[6] = sf.p.y; out[7] = sf.p.z; out[8] = sf.n.x; out[9] = sf.n.y; out[10] = sf.n.z;
+            }
+            continue;
+        }
         if (in[6] == 0.001) {
             const int32_t pos = wb.hit_tri[k];
             if (pos == kHitRedo) {
@@ -1326,7 +1428,8 @@ hipError_t wf_rays_in(const double* rays, uint32_t n, const WfBuffers& wb, doubl
     return hipGetLastError();
 }
 hipError_t wf_hits_out(const SceneDev& sc, const double* rays, uint32_t n, const WfBuffers& wb, double* hits, hipStream_t st) {
-    hipLaunchKernelGGL(k_hits_out, dim3(batch_grid(n)), dim3(kBlock), 0, st, sc, rays, n, wb, hits);
+    if (sc.objs) hipLaunchKernelGGL(k_hits_out<true>, dim3(batch_grid(n)), dim3(kBlock), 0, st, sc, rays, n, wb, hits);
+    else hipLaunchKernelGGL(k_hits_out<false>, dim3(batch_grid(n)), dim3(kBlock), 0, st, sc, rays, n, wb, hits);
     return hipGetLastError();
 }
 hipError_t wf_pairs_in(const double* pairs, uint32_t n, const WfBuffers& wb, hipStream_t st) {
@@ -1340,9 +1443,9 @@ hipError_t wf_visible_out(const WfBuffers& wb, uint32_t n, uint8_t* out, hipStre
 
 // Sets the LDS limit of one traversal kernel (more than 64 KiB of dynamic LDS has to be requested) and reports
 // how many of its workgroups fit a CU.
-template <bool SHADOW, bool STATS, bool LDS_SCENE>
+template <bool SHADOW, bool STATS, bool LDS_SCENE, bool INSTANCED = false>
 static hipError_t prepare_traverse(size_t shm, int* blocks_per_cu) {
-    auto fn = k_traverse<SHADOW, STATS, LDS_SCENE>;
+    auto fn = k_traverse<SHADOW, STATS, LDS_SCENE, INSTANCED>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     if (blocks_per_cu) {
@@ -1364,7 +1467,12 @@ static size_t traverse_lds_bytes(const WfLaunchCfg& cfg) {
 hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu) {
     const size_t shm = traverse_lds_bytes(cfg);
     hipError_t e;
-    if (cfg.lds_scene) {
+    if (cfg.instanced) {
+        e = prepare_traverse<false, false, false, true>(shm, blocks_per_cu);
+        if (e == hipSuccess) e = prepare_traverse<false, true, false, true>(shm, nullptr);
+        if (e == hipSuccess) e = prepare_traverse<true, false, false, true>(shm, nullptr);
+        if (e == hipSuccess) e = prepare_traverse<true, true, false, true>(shm, nullptr);
+    } else if (cfg.lds_scene) {
         e = prepare_traverse<false, false, true>(shm, blocks_per_cu);
         if (e == hipSuccess) e = prepare_traverse<false, true, true>(shm, nullptr);
         if (e == hipSuccess) e = prepare_traverse<true, false, true>(shm, nullptr);
@@ -1384,11 +1492,11 @@ hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers&
     return hipGetLastError();
 }
 
-template <bool SHADOW, bool STATS, bool LDS_SCENE>
+template <bool SHADOW, bool STATS, bool LDS_SCENE, bool INSTANCED = false>
 static void launch_traverse_as(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                                uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
                                hipStream_t st) {
-    hipLaunchKernelGGL((k_traverse<SHADOW, STATS, LDS_SCENE>), dim3(cfg.persistent_blocks), dim3(kBlock), traverse_lds_bytes(cfg), st,
+    hipLaunchKernelGGL((k_traverse<SHADOW, STATS, LDS_SCENE, INSTANCED>), dim3(cfg.persistent_blocks), dim3(kBlock), traverse_lds_bytes(cfg), st,
                        sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.top_nodes,
                        cfg.leaf_threshold, cfg.leaf_inner, (uint32_t)scene_lds_bytes(cfg), cfg.lds_stack);
 }
@@ -1397,7 +1505,10 @@ template <bool SHADOW>
 static hipError_t launch_traverse(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                                   uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
                                   hipStream_t st) {
-    if (stats) {
+    if (cfg.instanced) {
+        if (stats) launch_traverse_as<SHADOW, true, false, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+        else launch_traverse_as<SHADOW, false, false, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+    } else if (stats) {
         if (cfg.lds_scene) launch_traverse_as<SHADOW, true, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
         else launch_traverse_as<SHADOW, true, false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
     } else {
@@ -1423,6 +1534,16 @@ hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& w
                     hipStream_t st) {
     dim3 grid(cfg.stream_blocks), block(kStageBlock);
     const int last = last_bounce ? 1 : 0, keep = store_vertices ? 1 : 0;
+    if (cfg.instanced) {
+        if (eye) {
+            if (stats) hipLaunchKernelGGL((k_shade<true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+            else hipLaunchKernelGGL((k_shade<true, false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        } else {
+            if (stats) hipLaunchKernelGGL((k_shade<false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+            else hipLaunchKernelGGL((k_shade<false, false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        }
+        return hipGetLastError();
+    }
     if (eye) {
         if (stats) hipLaunchKernelGGL((k_shade<true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
         else if (store_vertices) hipLaunchKernelGGL((k_shade<true, false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);

@@ -85,6 +85,55 @@ def test_hits_match_reference(case):
     assert_bit_equal(hits2, hits, name + ": counting and plain query kernels")
 
 
+PIPELINE_CASES = ("cx_instances", "cx_lattice")      # instances only: these also run on the render pipeline
+
+
+def test_adversarial_queries_match_reference_on_both_walkers(case, ctx):
+    """Rays through transformed vertices, along edges, through corners of the world tree's boxes, axis-parallel, ending
+    at a hit distance up to an ulp; pairs that end on surfaces, pass through vertices or lie on one face: the pipeline's
+    traversal kernels (instances: the ray transform in front of the triangle test, exact ties re-checked against the
+    reference's two-level tree) and the walk in the reference's own order must both return the reference's answers."""
+    name, flat, sc, g = case
+    ref = g["adv_hits"]
+    for walker in (capi.WALKER_PIPELINE, capi.WALKER_REFERENCE_TREE):
+        ctx.set_query_walker(walker)
+        try:
+            hits = sc.trace_closest(g["adv_rays"])
+            vis = sc.visible(g["adv_pairs"])
+        finally:
+            ctx.set_query_walker(capi.WALKER_PIPELINE)
+        assert np.array_equal(hits[:, 0], ref[:, 0]), "%s walker %d: hit ids differ at %s" % (name, walker, np.flatnonzero(hits[:, 0] != ref[:, 0])[:8])
+        surface = ref[:, 0] != -1
+        assert_bit_equal(hits[surface][:, [1, 4, 5, 6, 7, 8, 9, 10]], ref[surface][:, [1, 4, 5, 6, 7, 8, 9, 10]], "%s walker %d" % (name, walker))
+        tri = ref[:, 0] >= 0
+        assert_bit_equal(hits[tri][:, 2:4], ref[tri][:, 2:4], "%s walker %d: u, v" % (name, walker))
+        bad = np.flatnonzero(vis != g["adv_visible"])
+        assert len(bad) == 0, "%s walker %d: %d of %d visibility answers differ, first %s" % (name, walker, len(bad), len(vis), bad[:8])
+
+
+def test_instances_render_on_the_pipeline(case):
+    """Scenes with instances only take the wavefront pipeline by default (its traversal launches can be timed, which
+    the single kernel has none of) and the single kernel on request; both give the reference's framebuffer."""
+    import torch
+    name, flat, sc, g = case
+    cam = capi.camera_initialize(flat.camera)
+    seed = int(g["render_seed"][0])
+    fb = torch.zeros(g["framebuffer"].shape, dtype=torch.float64, device="cuda")
+    sc.render_device(cam, fb.data_ptr(), seed=seed, time_stages=True)
+    torch.cuda.synchronize()
+    if name in PIPELINE_CASES:
+        ms, launches = sc.last_stage_ms(0)
+        assert launches > 0
+        assert_bit_equal(fb.cpu().numpy(), g["framebuffer"], name + ": pipeline")
+        fb_work, st = sc.render(cam, seed=seed, want_stats="work")
+        assert_bit_equal(fb_work, g["framebuffer"], name + ": pipeline, counting its work")
+        assert st.as_dict()["shadow_rays"] > 0
+    else:
+        with pytest.raises(capi.BdptError):
+            sc.last_stage_ms(0)
+    assert_bit_equal(sc.render(cam, seed=seed, megakernel=True), g["framebuffer"], name + ": single kernel")
+
+
 def test_visibility_matches_reference(case):
     name, flat, sc, g = case
     vis = sc.visible(g["pairs"])
@@ -146,6 +195,42 @@ def test_sharded_render_sums_to_the_whole(case):
     for r in range(3):
         total += sc.render(cam, seed=seed, shard=(r, 3, 2))
     assert_bit_equal(total, g["framebuffer"], name)
+
+
+def test_large_instanced_lattice_pipeline_equals_single_kernel(ctx, scenes):
+    """512 translate wrappers over six shared sphere meshes (0.49 M (object, triangle) pairs, far beyond any fixture): the
+    pipeline's framebuffer, hit records and visibility answers against the single kernel's walk in the reference's
+    own order, and row-band shards of the pipeline summing to the whole frame."""
+    flat = scenes.sphere_lattice_instanced(8, 96, 4, 8)
+    sc = ctx.scene(flat)
+    cam = capi.camera_initialize(flat.camera)
+    fb = sc.render(cam, seed=9)
+    assert_bit_equal(fb, sc.render(cam, seed=9, megakernel=True), "pipeline against single kernel")
+    assert fb.mean() > 0
+    total = np.zeros_like(fb)
+    for r in range(2):
+        total += sc.render(cam, seed=9, shard=(r, 2, 4))
+    assert_bit_equal(total, fb, "shards")
+    rng = np.random.default_rng(3)
+    ext = 3.0 * 8
+    n = 20000
+    o = rng.uniform(-0.5 * ext, 1.5 * ext, (n, 3))
+    tgt = rng.uniform(0, ext, (n, 3))
+    rays = np.concatenate([o, tgt - o, np.full((n, 1), 0.001), np.full((n, 1), np.inf)], axis=1)
+    hits = sc.trace_closest(rays)
+    ctx.set_query_walker(capi.WALKER_REFERENCE_TREE)
+    try:
+        ref = sc.trace_closest(rays)
+        surf = hits[hits[:, 0] >= 0][:, 5:8]
+        pairs = np.concatenate([surf[rng.integers(0, len(surf), 8000)], surf[rng.integers(0, len(surf), 8000)]], axis=1)
+        vis_ref = sc.visible(pairs)
+    finally:
+        ctx.set_query_walker(capi.WALKER_PIPELINE)
+    assert (hits[:, 0] >= 0).sum() > n // 4
+    assert_bit_equal(hits, ref, "hit records")
+    assert np.array_equal(sc.visible(pairs), vis_ref)
+    assert 0 < vis_ref.sum() < len(vis_ref)
+    sc.close()
 
 
 def test_refusals(ctx, scenes):
