@@ -241,13 +241,17 @@ typedef struct bdpt_object {
  * the SAME range: they share one mesh (one bvh_node behind several wrappers, as shared_ptr allows in the reference)
  * and stand in the list in the order of their indices; different ranges must not overlap.  Light triangles (the `lights` collection) must be triangles that
  * belong to no object; n_lights == 0 selects all of those.
- * The resulting scene renders through every bdpt_render* entry point except bdpt_render_device_static, on the
- * single-kernel path (one thread per sample, the reference's own traversal order: constant_medium::hit draws its
- * random number INSIDE the BVH walk, constant_medium.h:40, so the visiting order is part of the result) and answers
- * bdpt_trace_closest* / bdpt_visible; query i draws from stream (seed 0, pixel i, sample 0).  A hit inside a
- * medium reports -(2 + object index) as its triangle id and u = v = 0 (the reference leaves them unset).
- * BDPT_RENDER_UNIDIRECTIONAL selects camera::path_trace_color as for other scenes.  An isotropic material with an image texture
- * is refused: the reference reads unset u, v there (constant_medium.h:45-50, material.h:155). */
+ * How the resulting scene is rendered depends on what it holds.  Instances only (no medium, no texture): the
+ * wavefront pipeline, like any other scene - its traversal kernels transform the ray in front of an instanced
+ * triangle's test, and every bdpt_render* entry point and flag applies.  A medium or a texture: the single-kernel path
+ * (one thread per sample, the reference's own traversal order - constant_medium::hit draws its random number INSIDE
+ * the BVH walk, constant_medium.h:40, so the visiting order is part of the result; textures are simply not carried by
+ * the pipeline's records); bdpt_render_device_static, BDPT_RENDER_TIME_STAGES and BDPT_RENDER_COUNT_WORK's meaning do
+ * not apply there.  For a composite scene BDPT_RENDER_MEGAKERNEL, BDPT_RENDER_COUNT_STATS and
+ * BDPT_RENDER_UNIDIRECTIONAL always take the single kernel.  bdpt_trace_closest* / bdpt_visible answer for every composite scene; query i draws from stream
+ * (seed 0, pixel i, sample 0).  A hit inside a medium reports -(2 + object index) as its triangle id and u = v = 0 (the
+ * reference leaves them unset); a hit on a shared mesh reports the triangle of the mesh.
+ * An isotropic material with an image texture is refused: the reference reads unset u, v there (constant_medium.h:45-50, material.h:155). */
 int bdpt_scene_create_composite(bdpt_context* ctx, const double* tri_vertices, const int32_t* tri_material,
                                 uint32_t n_triangles, const bdpt_material* materials, uint32_t n_materials,
                                 const bdpt_texture* textures, uint32_t n_textures, const bdpt_object* objects,
