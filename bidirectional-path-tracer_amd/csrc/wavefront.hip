@@ -466,6 +466,10 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
     uint32_t pool_next = 0, pool_end = 0;     // wave-uniform
     if (first_base < count) { pool_next = first_base; pool_end = (first_base + kChunk < count) ? first_base + kChunk : count; }
     bool exhausted = (pool_next == pool_end);
+    // INSTANCED: the ray as the object of the last tested triangle sees it (the triangles of a leaf nearly always
+    // belong to one object, and a wave stays with a leaf's triangles for several iterations)
+    int32_t cached_ob = -1;
+    V3 cached_o = mk(0, 0, 0), cached_d = mk(0, 0, 0);
     uint32_t n_records = 0, n_box_hits = 0, n_tri = 0, n_tri_hits = 0, n_rays = 0;
 #ifdef BDPT_AB_COUNT_REDO
     uint32_t n_redo = 0;
@@ -507,6 +511,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                     }
                     if (!SHADOW || tmax0 >= 0.0) {              // a negative max_t marks an unused queue entry
                         rf = ray_f32(o, d, bound_f32);
+                        if (INSTANCED) cached_ob = -1;
                         closest = tmax0;
                         cur = 0;
                         leaf_left = 0;
@@ -571,7 +576,14 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                 V3 to = o, td = d;
                 if (INSTANCED) {
                     const int32_t ob = sc.xobj[leaf_next];
-                    if (ob >= 0) cx_to_object(sc.objs[ob], to, td);
+                    if (ob >= 0) {
+                        if (ob != cached_ob) {
+                            cached_o = o; cached_d = d;
+                            cx_to_object(sc.objs[ob], cached_o, cached_d);
+                            cached_ob = ob;
+                        }
+                        to = cached_o; td = cached_d;
+                    }
                 }
                 leaf_next++;
                 leaf_left--;
