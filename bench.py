@@ -76,6 +76,8 @@ WORKLOADS = {
     "sphere-lattice-instanced-10m-4096": (None, "sphere_lattice_instanced", dict(n_side=22, image_width=4096, samples_per_pixel=64, max_depth=10),
                                           "the same lattice as the reference's object model writes it: 10 648 translate instances sharing six 960-triangle meshes "
                                           "(10.2 M triangles once instanced), 4096x4096, 64 spp, max depth 10 (configuration 5 as worded)"),
+    "sphere-lattice-instanced-1m-1024": (None, "sphere_lattice_instanced", dict(n_side=10, image_width=1024, samples_per_pixel=64, max_depth=10),
+                                         "1 000 translate instances sharing six sphere meshes (0.96 M triangles once instanced), 1024x1024, 64 spp, max depth 10"),
     "sphere-lattice-1m-1024": (None, "sphere_lattice", dict(n_side=10, image_width=1024, samples_per_pixel=64, max_depth=10),
                                "10^3 lambertian spheres (0.96 M triangles), 1024x1024, 64 spp, max depth 10"),
     "glass-of-water-256": ("glass-of-water.yaml", "glass_of_water_standin", dict(image_width=256, image_height=256, samples_per_pixel=16, max_depth=4),

@@ -76,12 +76,13 @@ BDPT_DEV void cx_to_object(const CxObject& ob, V3& o, V3& d) {
 }
 
 // hit() of one object of the world's list
-template <int STATS, bool ANYHIT = false, class Sc>
+// MEDIA = false: for scenes known to hold no medium (the medium's code, its logarithm included, is left out)
+template <int STATS, bool ANYHIT = false, bool MEDIA = true, class Sc>
 BDPT_DEV bool cx_object_hit(const Sc& sc, int32_t k, V3 o, V3 d, double tmin, double tmax, CxHit& hit, Counters& c, Rng& rng) {
     const CxObject ob = sc.objs[k];
     V3 oo = o, od = d;
     cx_to_object(ob, oo, od);
-    if (!(ob.flags & kCxMedium)) {
+    if (!MEDIA || !(ob.flags & kCxMedium)) {
         CxHit h;
         if (!cx_walk_mesh<STATS, ANYHIT>(sc, ob.root, oo, od, tmin, tmax, h, c)) return false;
         hit = h;
@@ -109,7 +110,7 @@ BDPT_DEV bool cx_object_hit(const Sc& sc, int32_t k, V3 o, V3 d, double tmin, do
 }
 
 // bvh_node::hit over the world's tree: leaves are triangles or objects
-template <int STATS, bool ANYHIT = false, class Sc>
+template <int STATS, bool ANYHIT = false, bool MEDIA = true, class Sc>
 BDPT_DEV bool cx_walk(const Sc& sc, V3 o, V3 d, double tmin, double tmax, CxHit& hit, Counters& c, Rng& rng) {
     const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;
     double closest = tmax;
@@ -148,7 +149,7 @@ BDPT_DEV bool cx_walk(const Sc& sc, V3 o, V3 d, double tmin, double tmax, CxHit&
                     if (h) { if (ANYHIT) return true; closest = t; hit.t = t; hit.u = u; hit.v = v; hit.tri = ref; hit.obj = -1; any = true; }
                 } else {
                     CxHit h;
-                    if (cx_object_hit<STATS, ANYHIT>(sc, -(ref + 2), o, d, tmin, closest, h, c, rng)) { if (ANYHIT) return true; closest = h.t; hit = h; any = true; }
+                    if (cx_object_hit<STATS, ANYHIT, MEDIA>(sc, -(ref + 2), o, d, tmin, closest, h, c, rng)) { if (ANYHIT) return true; closest = h.t; hit = h; any = true; }
                 }
             }
         }

@@ -392,7 +392,7 @@ struct GlobalRefTree {
 // Scenes with instances: the chain of boxes above an entry of `stris` runs through the mesh's own tree with the ray as
 // the mesh sees it (translate::hit / rotate_y::hit hand the interval on unchanged, hittable.h:54-66,110-148) and then
 // through the world's tree, from the node that holds the object, with the ray itself.
-__device__ __attribute__((noinline)) bool instanced_reaches(const SceneDev& sc, uint32_t pos, V3 o, V3 d, double max_t) {
+BDPT_DEV bool instanced_reaches(const SceneDev& sc, uint32_t pos, V3 o, V3 d, double max_t) {
     const uint32_t leaf = sc.sleaf[pos];
     const int32_t ob = sc.pos_obj[pos];
     if (ob < 0) return reference_reaches(sc, leaf, o, d, max_t);
@@ -763,12 +763,12 @@ __device__ __attribute__((noinline)) int32_t redo_closest(const SceneDev& sc, V3
 
 // The same for a scene with instances: the walk over the two-level table; returns the POSITION of the hit entry in
 // the leaf order (or -1) and which object it belongs to.
-__device__ __attribute__((noinline)) int32_t redo_closest_instanced(const SceneDev& sc, V3 o, V3 d, double tmin, double tmax, CxHit& h) {
+BDPT_DEV int32_t redo_closest_instanced(const SceneDev& sc, V3 o, V3 d, double tmin, double tmax, CxHit& h) {
     Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     Rng unused;
     unused.key = 0; unused.counter = 0;            // (only a medium draws, and scenes with media do not run here)
     h.tri = -1; h.obj = -1; h.t = 0; h.u = 0; h.v = 0;
-    if (!cx_walk<kStatsOff>(sc, o, d, tmin, tmax, h, c, unused)) return -1;
+    if (!cx_walk<kStatsOff, false, false>(sc, o, d, tmin, tmax, h, c, unused)) return -1;
     return (int32_t)((h.obj >= 0 ? sc.obj_pos0[h.obj] : 0u) + sc.tri_pos[h.tri]);
 }
 // hit_record of an entry of the leaf order that belongs to an object: position and normal as translate::hit /
@@ -786,6 +786,25 @@ BDPT_DEV void instanced_surface(const SceneDev& sc, int32_t ob, V3 outward, V3 o
         normal = mk((c * normal.x) + (sn * normal.z), normal.y, (-sn * normal.x) + (c * normal.z));
     }
     if (obj.flags & kCxTranslate) p = add(p, ld3(obj.offset));
+}
+
+// Scenes with instances: the rays of a queue that the traversal kernel marked kHitRedo are traced here with the
+// two-level walk in the reference's own order, in a kernel of their own - that walk needs twice the registers of a
+// shading kernel, and a shading kernel that carried it would no longer fit beside the resident traversal waves.
+__global__ __launch_bounds__(kBlock) void k_redo_instanced(SceneDev sc, WfBuffers wb, const uint32_t* queue, const uint32_t* count_ptr,
+                                                          uint32_t count_imm) {
+    const uint32_t count = count_ptr ? *count_ptr : count_imm;
+    const uint64_t ns = wb.ns;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
+        const uint32_t slot = queue ? queue[k] : k;
+        if (wb.hit_tri[slot] != kHitRedo) continue;
+        CxHit rh;
+        const int32_t pos = redo_closest_instanced(sc, mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]),
+                                                   mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]), 0.001,
+                                                   wb.tmax ? wb.tmax[slot] : kInf, rh);
+        wb.hit_tri[slot] = pos;
+        if (pos >= 0) wb.hit[slot] = rh.t;
+    }
 }
 
 // ------------------------------------------------------------------ shading of one bounce
@@ -814,17 +833,10 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             if (!slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
             int32_t pos = wb.hit_tri[slot];           // position of the hit triangle in the reference's leaf order
             double t_hit = 0.0;
-            if (pos == kHitRedo) {
-                if (INSTANCED) {
-                    CxHit rh;
-                    pos = redo_closest_instanced(sc, mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]),
-                                                 mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]), 0.001, kInf, rh);
-                    t_hit = rh.t;
-                } else {
-                    const int32_t tri = redo_closest(sc, mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]),
-                                                     mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]), kInf, t_hit);
-                    pos = tri < 0 ? -1 : (int32_t)sc.tri_pos[tri];
-                }
+            if (!INSTANCED && pos == kHitRedo) {       // (scenes with instances: k_redo_instanced has been over the queue already)
+                const int32_t tri = redo_closest(sc, mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]),
+                                                 mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]), kInf, t_hit);
+                pos = tri < 0 ? -1 : (int32_t)sc.tri_pos[tri];
             } else if (pos >= 0) t_hit = wb.hit[slot];
             V3 T = mk(wb.thr[slot], wb.thr[ns + slot], wb.thr[2 * ns + slot]);
             if (pos < 0) {
@@ -839,18 +851,26 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             const uint32_t ctr0 = wb.ctr[slot];
             Rng rng = slot_rng(cam, b, slot, ctr0);
             Bounce bo;
-            const int32_t ob = INSTANCED ? sc.pos_obj[pos] : -1;
-            if (INSTANCED && ob >= 0) {
+            if (INSTANCED) {
+                // one copy of the material code: the hit_record first (through the object's wrappers or not), then shading
                 const GpuShadeRec r = sc.shade[pos];
                 ShadeMat m;
                 m.normal = ld3(r.normal); m.rgb = ld3(r.rgb); m.fuzz = r.param; m.ior = r.param;
                 m.type = (int32_t)(r.mat >> 30); m.id = (int32_t)(r.mat & kVtxMatMask);
+                const int32_t ob = sc.pos_obj[pos];
                 V3 p, normal;
                 bool front_face;
-                instanced_surface(sc, ob, m.normal, o, d, t_hit, p, normal, front_face);
+                if (ob >= 0) {
+                    instanced_surface(sc, ob, m.normal, o, d, t_hit, p, normal, front_face);
+                } else {
+                    p = add(o, scl(t_hit, d));
+                    front_face = dot(d, m.normal) < 0;
+                    normal = front_face ? m.normal : neg(m.normal);
+                }
                 shade_surface<EYE, LAMBERT>(m, (int32_t)r.tri, p, normal, front_face, d, T, rng, bo);
-            } else
-            shade_bounce_at<EYE, LAMBERT>(sc, (uint32_t)pos, o, d, t_hit, T, rng, bo);
+            } else {
+                shade_bounce_at<EYE, LAMBERT>(sc, (uint32_t)pos, o, d, t_hit, T, rng, bo);
+            }
             // state that a bounce leaves as it was is not written again (a specular bounce keeps no vertex, a
             // dielectric one leaves the throughput alone: x * 1.0 is x)
             if (bo.keep && store_vertices) {       // (no vertex store in a scene that cannot form a connection)
@@ -1332,7 +1352,7 @@ __global__ __launch_bounds__(kBlock) void k_hits_out(SceneDev sc, const double* 
         HitLite h;
         h.tri = -1; h.t = 0; h.u = 0; h.v = 0;
         if (INSTANCED) {
-            int32_t pos = (in[6] == 0.001) ? wb.hit_tri[k] : kHitRedo;
+            int32_t pos = (in[6] == 0.001) ? wb.hit_tri[k] : kHitRedo;      // (k_redo_instanced has resolved the traversal kernel's own marks)
             CxHit ch;
             ch.tri = -1; ch.obj = -1; ch.t = 0; ch.u = 0; ch.v = 0;
             if (pos == kHitRedo) {
@@ -1532,7 +1552,12 @@ static hipError_t launch_traverse(const SceneDev& sc, const WfBuffers& wb, const
 
 hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                      uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    return launch_traverse<false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+    hipError_t e = launch_traverse<false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+    if (e == hipSuccess && cfg.instanced) {
+        hipLaunchKernelGGL(k_redo_instanced, dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, wb, queue, count_ptr, count_imm);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t count_imm, uint32_t* cursor,
