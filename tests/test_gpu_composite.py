@@ -233,6 +233,21 @@ def test_large_instanced_lattice_pipeline_equals_single_kernel(ctx, scenes):
     sc.close()
 
 
+def test_composite_without_objects_equals_plain_scene(ctx, scenes):
+    """A composite scene with no object and no texture is the plain triangle soup: the same tables, the same kernels
+    (the Cornell box is small enough for the variants that keep the whole scene in LDS), the same bits."""
+    plain = scenes.cornell_box(24, 16, 6)
+    comp = scenes.CompositeScene(materials=plain.materials, vertices=plain.vertices, tri_material=plain.tri_material,
+                                 lights=plain.lights, camera=plain.camera)
+    a, b = ctx.scene(plain), ctx.scene(comp)
+    cam = capi.camera_initialize(plain.camera)
+    assert_bit_equal(b.render(cam, seed=2), a.render(cam, seed=2), "pipeline")
+    assert_bit_equal(b.render(cam, seed=2, megakernel=True), a.render(cam, seed=2), "single kernel of composite scenes")
+    assert np.array_equal(a.dfs_leaves().astype(np.int64), b.dfs_leaves().astype(np.int64))
+    assert_bit_equal(a.node_boxes(), b.node_boxes(), "tree")
+    a.close(); b.close()
+
+
 def test_refusals(ctx, scenes):
     bad, _ = composite_scene(scenes, "cx_textures")
     bad.materials[0].type = scenes.ISOTROPIC          # a surface triangle with a phase function
