@@ -1,28 +1,33 @@
-# Evidence of one round: bash tools/profile_round.sh <tag>  ->  gpurun_out/<tag>/ (copy what is to be kept into profiles/<tag>/)
-#  bench_line_default.json          the default bench.py run (all legs: roofline with its counter passes, extras, CPU baseline)
-#  kernel_stats_bench_default.csv   rocprofv3 --kernel-trace --stats of the default workload (4 batches in flight)
-#  kernel_stats_one_<workload>.csv  the same with one batch in flight (kernels back to back), per workload
-#  bench_line_<workload>.json       bench lines of the other workloads
+# Evidence of one round: bash tools/profile_round.sh <tag> [lines|stats]  ->  gpurun_out/<tag>/ (copy what is to be kept into profiles/<tag>/)
+#  lines:  bench_line_default.json     the default bench.py run (all legs: roofline with its counter passes, extras, CPU baseline)
+#          bench_line_<workload>.json  bench lines of the other workloads, each with its own counter passes (roofline.traffic)
+#  stats:  kernel_stats_bench_default.csv   rocprofv3 --kernel-trace --stats of the default workload (4 batches in flight)
+#          kernel_stats_one_<workload>.csv  the same with one batch in flight (kernels back to back), per workload
 R=$GRAFT_REPO_ROOT
 T=$1
+PART=${2:-all}
 O=$R/gpurun_out/$T
 mkdir -p $O
 cd $R
-timeout -k 10 900 python3 bench.py > $O/bench_line_default.json 2> $O/bench_default.err || exit 1
-echo default done
-for W in cornell-512 coffee-machine-1080p sphere-lattice-1m-1024; do
-  timeout -k 10 300 python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-pmc > $O/bench_line_$W.json 2> $O/bench_$W.err || exit 1
-done
-echo lines done
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-pmc > $O/bench_line_under_rocprof.json 2> $O/kt.err || exit 1
-cp $O/kt/*/*_kernel_stats.csv $O/kernel_stats_bench_default.csv
-rm -rf $O/kt
-echo kt done
-export BDPT_WF_STREAMS=1
-for W in glass-of-water-1080p cornell-512 coffee-machine-1080p sphere-lattice-1m-1024; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python3 $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-extras --no-pmc > /dev/null 2> $O/kt1.err || exit 1
-  cp $O/kt1/*/*_kernel_stats.csv $O/kernel_stats_one_$W.csv
-  rm -rf $O/kt1
-done
+if [ "$PART" = all ] || [ "$PART" = lines ]; then
+  timeout -k 10 900 python3 bench.py > $O/bench_line_default.json 2> $O/bench_default.err || exit 1
+  echo default done
+  for W in cornell-512 coffee-machine-1080p sphere-lattice-1m-1024 sphere-lattice-10m-4096 sphere-lattice-instanced-10m-4096; do
+    timeout -k 10 600 python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_line_$W.json 2> $O/bench_$W.err || exit 1
+    echo $W done
+  done
+fi
+if [ "$PART" = all ] || [ "$PART" = stats ]; then
+  cd /tmp && export TMPDIR=/tmp
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-pmc > $O/bench_line_under_rocprof.json 2> $O/kt.err || exit 1
+  cp $O/kt/*/*_kernel_stats.csv $O/kernel_stats_bench_default.csv
+  rm -rf $O/kt
+  echo kt done
+  export BDPT_WF_STREAMS=1
+  for W in glass-of-water-1080p cornell-512 coffee-machine-1080p sphere-lattice-1m-1024 sphere-lattice-instanced-10m-4096; do
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python3 $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-extras --no-pmc > /dev/null 2> $O/kt1.err || exit 1
+    cp $O/kt1/*/*_kernel_stats.csv $O/kernel_stats_one_$W.csv
+    rm -rf $O/kt1
+  done
+fi
 echo all done
