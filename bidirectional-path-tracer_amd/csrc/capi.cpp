@@ -292,6 +292,7 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     cfg.leaf_inner = kn.leaf_inner > 0 ? kn.leaf_inner : (cfg.leaf_threshold > 1 ? cfg.leaf_threshold / 2 : 1);
     cfg.chunk = (uint32_t)kn.chunk;   // measured: the cursor is one address, and its atomics cost more than a coarser split
     cfg.stream_blocks = ctx->cu_count * 8;
+    cfg.redo_blocks = ctx->cu_count * 8;
     return BDPT_OK;
 }
 
@@ -330,7 +331,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 6 + vslots * 10 * sizeof(double) +
                             vis_words * sizeof(unsigned long long) + (shadow_per_slot * 8 + kept_per_slot * 3) * sizeof(double) +
                             (connections ? 8 : 0);        // (the slack of the shadow queue, see conn_blocks below)
-    const size_t n_counters = 8 + 6 * (size_t)(depth > 0 ? depth : 1);
+    const size_t n_counters = 8 + 8 * (size_t)(depth > 0 ? depth : 1);      // (+ one k_redo list size per closest-hit traversal launch)
     // Wavefront state of all batches in flight.  Large batches mean few, long launches (a frame is tens of thousands
     // of them), so a host that wants the last tenth of throughput raises the limit (bdpt_context_set_workspace_limit).
     size_t budget;
@@ -492,6 +493,8 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         auto light_cursor = [&](int k) { return C + 8 + 2 * depth + 2 * k + 1; };
         auto shadow_count = [&](int a) { return C + 8 + 4 * depth + 2 * a; };
         auto shadow_cursor = [&](int a) { return C + 8 + 4 * depth + 2 * a + 1; };
+        auto eye_redo = [&](int k) { return C + 8 + 6 * depth + k; };
+        auto light_redo = [&](int k) { return C + 8 + 7 * depth + k; };
         uint32_t* conn_count = C;
 
         WfBatch b;
@@ -511,8 +514,8 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         for (int k = 0; k < depth && unidirectional; k++) {
             const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
             const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
-            { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
             const int nxt = (k == 0) ? 0 : (cur ^ 1);
+            { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st, wb.queue[nxt], eye_redo(k)); }); if (rc != BDPT_OK) return rc; }
             HIP_TRY(wf_shade_unidirectional(scene->dev, gcam, wb, b, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k, k == depth - 1, cfg, stats, st));
             cur = nxt;
         }
@@ -520,8 +523,8 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         for (int k = 0; k < depth && !unidirectional; k++) {
             const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
             const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
-            { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
             const int nxt = (k == 0) ? 0 : (cur ^ 1);
+            { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st, wb.queue[nxt], eye_redo(k)); }); if (rc != BDPT_OK) return rc; }
             HIP_TRY(wf_shade(scene->dev, gcam, wb, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, connections, cfg,
                              stats, st));
             cur = nxt;
@@ -531,7 +534,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
             HIP_TRY(wf_gen_light(scene->dev, gcam, wb, b, wb.queue[0], light_count(0), cfg, stats, st));
             cur = 0;
             for (int k = 0; k < depth - 1; k++) {
-                { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
+                { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st, wb.queue[cur ^ 1], light_redo(k)); }); if (rc != BDPT_OK) return rc; }
                 HIP_TRY(wf_shade(scene->dev, gcam, wb, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
                                  light_count(k + 1), k == depth - 2, true, cfg, stats, st));
                 cur ^= 1;
@@ -636,7 +639,8 @@ int trace_closest_pipeline(bdpt_context* ctx, const bdpt_scene* scene, const dou
     const uint64_t piece = n < kQueryPiece ? n : kQueryPiece;
     size_t off = 0;
     auto take = [&off](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
-    const size_t o_ray = take(piece * 6 * 8), o_tmax = take(piece * 8), o_hit = take(piece * 8), o_tri = take(piece * 4), o_cur = take(256);   // cursor, then the ray length bound
+    const size_t o_ray = take(piece * 6 * 8), o_tmax = take(piece * 8), o_hit = take(piece * 8), o_tri = take(piece * 4), o_redo = take(piece * 4),
+                 o_cur = take(256);   // cursor, the ray length bound, the size of k_redo's list
     { int rc = ensure_query_ws(ctx, off); if (rc != BDPT_OK) return rc; }
     char* base = static_cast<char*>(ctx->query_ws);
     WfBuffers wb{};
@@ -652,9 +656,9 @@ int trace_closest_pipeline(bdpt_context* ctx, const bdpt_scene* scene, const dou
     for (uint64_t first = 0; first < n; first += piece) {
         const uint32_t m = (uint32_t)(n - first < piece ? n - first : piece);
         const double* rays = d_rays + 8 * first;
-        HIP_TRY(hipMemsetAsync(cursor, 0, 2 * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(cursor, 0, 3 * sizeof(uint32_t), stream));
         HIP_TRY(wf_rays_in(rays, m, wb, tmax, ray_len, stream));
-        HIP_TRY(wf_extend(scene->dev, wb, nullptr, nullptr, m, cursor, cfg, nullptr, stream));
+        HIP_TRY(wf_extend(scene->dev, wb, nullptr, nullptr, m, cursor, cfg, nullptr, stream, reinterpret_cast<uint32_t*>(base + o_redo), cursor + 2));
         HIP_TRY(wf_hits_out(scene->dev, rays, m, wb, d_hits + 11 * first, stream));
     }
     return BDPT_OK;

@@ -430,7 +430,7 @@ template <bool SHADOW, bool STATS, bool INSTANCED, class Mem, class Ref>
 BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, uint32_t count,
                              uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk,
                              const int kLeafThreshold, const int kLeafInner, const double coord_bound, double* lds_stack, const int kLdsStack,
-                             const uint32_t first_base) {
+                             const uint32_t first_base, uint32_t* redo_list, uint32_t* redo_count) {
     const float bound_f32 = float_up(coord_bound);
     // upper bound of |d| over the rays of this launch (visibility rays have unit directions)
     const GrazeBits gbits = graze_bits(sc.bary_margin, SHADOW ? 1.0001f : (wb.ray_len_ptr ? *wb.ray_len_ptr : wb.ray_len));
@@ -646,6 +646,8 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                 if (STATS && redo) n_redo++;
 #endif
                 wb.hit_tri[slot] = redo ? kHitRedo : h.tri;      // position in the reference's leaf order (k_shade turns it into the triangle id)
+                // an exact tie: the ray goes on the list of k_redo, which traces it in the reference's own order
+                if (redo) redo_list[atomicAdd(redo_count, 1u)] = slot;
                 // the barycentric coordinates of the hit are not kept: nothing on this path reads them (the
                 // reference's hit_record carries u, v for textures, and every texture here is a solid colour)
                 if (!redo && h.tri >= 0) wb.hit[slot] = closest;
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
                                                     const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                     unsigned long long* stats, int refill_threshold, uint32_t chunk,
                                                     uint32_t top_nodes, int leaf_threshold, int leaf_inner, uint32_t scene_lds_bytes,
-                                                    int lds_stack) {
+                                                    int lds_stack, uint32_t* redo_list, uint32_t* redo_count) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
     double* const l_stack = reinterpret_cast<double*>(smem + scene_lds_bytes);     // [lds_stack + 1][kBlock]
@@ -728,11 +730,11 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
             // (the copy of the reference's tree lies behind the stack part; only visibility rays consult it)
             if (SHADOW) {
                 const RefTree ref = stage_ref_tree(sc, smem + scene_lds_bytes + (size_t)(lds_stack + 1) * kBlock * sizeof(double));
-                traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
+                traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
                 return;
             }
             const GlobalRefTree ref;
-            traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
+            traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
         } else {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
@@ -740,11 +742,11 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
             TopLdsMem<GpuQuadNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
             if (INSTANCED) {
                 const InstancedRefTree ref;
-                traverse_queue<SHADOW, STATS, true>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
+                traverse_queue<SHADOW, STATS, true>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
                 return;
             }
             const GlobalRefTree ref;
-            traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base);
+            traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
         }
     }
 }
@@ -788,22 +790,36 @@ BDPT_DEV void instanced_surface(const SceneDev& sc, int32_t ob, V3 outward, V3 o
     if (obj.flags & kCxTranslate) p = add(p, ld3(obj.offset));
 }
 
-// Scenes with instances: the rays of a queue that the traversal kernel marked kHitRedo are traced here with the
-// two-level walk in the reference's own order, in a kernel of their own - that walk needs twice the registers of a
-// shading kernel, and a shading kernel that carried it would no longer fit beside the resident traversal waves.
-__global__ __launch_bounds__(kBlock) void k_redo_instanced(SceneDev sc, WfBuffers wb, const uint32_t* queue, const uint32_t* count_ptr,
-                                                          uint32_t count_imm) {
-    const uint32_t count = count_ptr ? *count_ptr : count_imm;
+// The closest-hit rays of one traversal launch that met an exact tie (hit_tri == kHitRedo; the traversal kernel put
+// their slots on a list) are traced here in the reference's own order, densely: one listed ray per lane.  Inside the
+// kernels that read the hits a lane with such a ray kept the other 63 of its wave waiting for a walk over the
+// reference's median-split tree (13 % of the frame of a scene where two rays in a thousand tie), and the walk's registers
+// counted against kernels that have to fit beside the resident traversal waves.
+template <bool INSTANCED>
+__global__ __launch_bounds__(kBlock) void k_redo(SceneDev sc, WfBuffers wb, const uint32_t* list, const uint32_t* count_ptr) {
+    const uint32_t count = *count_ptr;
     const uint64_t ns = wb.ns;
-    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
-        const uint32_t slot = queue ? queue[k] : k;
-        if (wb.hit_tri[slot] != kHitRedo) continue;
-        CxHit rh;
-        const int32_t pos = redo_closest_instanced(sc, mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]),
-                                                   mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]), 0.001,
-                                                   wb.tmax ? wb.tmax[slot] : kInf, rh);
+    // Entry k goes to lane k / n_waves of wave k % n_waves: a short list is spread one ray per wave (such a walk is
+    // long and of its own shape, and the stream waits for the slowest wave), a long one fills the lanes.
+    const uint32_t n_waves = gridDim.x * (kBlock >> 6);
+    const uint32_t wave = blockIdx.x * (kBlock >> 6) + (threadIdx.x >> 6);
+    for (uint64_t k = wave + (uint64_t)n_waves * lane_id(); k < count; k += (uint64_t)n_waves * 64u) {
+        const uint32_t slot = list[k];
+        const V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
+        const V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
+        const double tmax = wb.tmax ? wb.tmax[slot] : kInf;
+        int32_t pos;
+        double t = 0.0;
+        if (INSTANCED) {
+            CxHit rh;
+            pos = redo_closest_instanced(sc, o, d, 0.001, tmax, rh);
+            t = rh.t;
+        } else {
+            const int32_t tri = redo_closest(sc, o, d, tmax, t);
+            pos = tri < 0 ? -1 : (int32_t)sc.tri_pos[tri];
+        }
         wb.hit_tri[slot] = pos;
-        if (pos >= 0) wb.hit[slot] = rh.t;
+        if (pos >= 0) wb.hit[slot] = t;
     }
 }
 
@@ -833,11 +849,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             if (!slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
             int32_t pos = wb.hit_tri[slot];           // position of the hit triangle in the reference's leaf order
             double t_hit = 0.0;
-            if (!INSTANCED && pos == kHitRedo) {       // (scenes with instances: k_redo_instanced has been over the queue already)
-                const int32_t tri = redo_closest(sc, mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]),
-                                                 mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]), kInf, t_hit);
-                pos = tri < 0 ? -1 : (int32_t)sc.tri_pos[tri];
-            } else if (pos >= 0) t_hit = wb.hit[slot];
+            if (pos >= 0) t_hit = wb.hit[slot];        // (k_redo has resolved the rays the traversal kernel left open)
             V3 T = mk(wb.thr[slot], wb.thr[ns + slot], wb.thr[2 * ns + slot]);
             if (pos < 0) {
                 if (EYE) {   // camera.h:337-338: background_contrib (0) += throughput * background
@@ -937,8 +949,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade_unidirectional(SceneDev s
             const int32_t pos = wb.hit_tri[slot];
             HitLite h;
             h.tri = pos < 0 ? -1 : sc.stris[pos].pad; h.t = 0; h.u = 0; h.v = 0;
-            if (pos == kHitRedo) h.tri = redo_closest(sc, o, d, kInf, h.t);
-            else if (pos >= 0) h.t = wb.hit[slot];
+            if (pos >= 0) h.t = wb.hit[slot];
             V3 value = mk(0, 0, 0);           // what the innermost level returns
             int n_records = level;
             Rng rng = slot_rng(cam, b, slot, wb.ctr[slot]);
@@ -1352,7 +1363,7 @@ __global__ __launch_bounds__(kBlock) void k_hits_out(SceneDev sc, const double* 
         HitLite h;
         h.tri = -1; h.t = 0; h.u = 0; h.v = 0;
         if (INSTANCED) {
-            int32_t pos = (in[6] == 0.001) ? wb.hit_tri[k] : kHitRedo;      // (k_redo_instanced has resolved the traversal kernel's own marks)
+            int32_t pos = (in[6] == 0.001) ? wb.hit_tri[k] : kHitRedo;      // (k_redo has resolved the traversal kernel's own marks)
             CxHit ch;
             ch.tri = -1; ch.obj = -1; ch.t = 0; ch.u = 0; ch.v = 0;
             if (pos == kHitRedo) {
@@ -1379,11 +1390,8 @@ __global__ __launch_bounds__(kBlock) void k_hits_out(SceneDev sc, const double* 
             continue;
         }
         if (in[6] == 0.001) {
-            const int32_t pos = wb.hit_tri[k];
-            if (pos == kHitRedo) {
-                GlobalScene mem{sc.nodes, sc.tris};
-                if (!walk<kStatsOff, false>(mem, o, d, in[6], in[7], h, c)) h.tri = -1;
-            } else if (pos >= 0) {
+            const int32_t pos = wb.hit_tri[k];      // (exact ties already resolved by k_redo)
+            if (pos >= 0) {
                 h.tri = sc.stris[pos].pad;
                 double t, u, v;
                 if (tri_test(sc.tris[h.tri], o, d, 0.001, kInf, t, u, v)) { h.t = t; h.u = u; h.v = v; }
@@ -1527,37 +1535,38 @@ hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers&
 template <bool SHADOW, bool STATS, bool LDS_SCENE, bool INSTANCED = false>
 static void launch_traverse_as(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                                uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
-                               hipStream_t st) {
+                               hipStream_t st, uint32_t* redo_list, uint32_t* redo_count) {
     hipLaunchKernelGGL((k_traverse<SHADOW, STATS, LDS_SCENE, INSTANCED>), dim3(cfg.persistent_blocks), dim3(kBlock), traverse_lds_bytes(cfg), st,
                        sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.top_nodes,
-                       cfg.leaf_threshold, cfg.leaf_inner, (uint32_t)scene_lds_bytes(cfg), cfg.lds_stack);
+                       cfg.leaf_threshold, cfg.leaf_inner, (uint32_t)scene_lds_bytes(cfg), cfg.lds_stack, redo_list, redo_count);
 }
 
 template <bool SHADOW>
 static hipError_t launch_traverse(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                                   uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
-                                  hipStream_t st) {
+                                  hipStream_t st, uint32_t* redo_list = nullptr, uint32_t* redo_count = nullptr) {
     if (cfg.instanced) {
-        if (stats) launch_traverse_as<SHADOW, true, false, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
-        else launch_traverse_as<SHADOW, false, false, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+        if (stats) launch_traverse_as<SHADOW, true, false, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+        else launch_traverse_as<SHADOW, false, false, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
     } else if (stats) {
-        if (cfg.lds_scene) launch_traverse_as<SHADOW, true, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
-        else launch_traverse_as<SHADOW, true, false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+        if (cfg.lds_scene) launch_traverse_as<SHADOW, true, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+        else launch_traverse_as<SHADOW, true, false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
     } else {
-        if (cfg.lds_scene) launch_traverse_as<SHADOW, false, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
-        else launch_traverse_as<SHADOW, false, false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
+        if (cfg.lds_scene) launch_traverse_as<SHADOW, false, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+        else launch_traverse_as<SHADOW, false, false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
     }
     return hipGetLastError();
 }
 
 hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
-                     uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    hipError_t e = launch_traverse<false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st);
-    if (e == hipSuccess && cfg.instanced) {
-        hipLaunchKernelGGL(k_redo_instanced, dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, wb, queue, count_ptr, count_imm);
-        e = hipGetLastError();
-    }
-    return e;
+                     uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st,
+                     uint32_t* redo_list, uint32_t* redo_count) {
+    hipError_t e = launch_traverse<false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+    if (e != hipSuccess) return e;
+    // few rays, if any: a small grid that returns at once when the list is empty
+    if (cfg.instanced) hipLaunchKernelGGL(k_redo<true>, dim3(cfg.redo_blocks), dim3(kBlock), 0, st, sc, wb, redo_list, redo_count);
+    else hipLaunchKernelGGL(k_redo<false>, dim3(cfg.redo_blocks), dim3(kBlock), 0, st, sc, wb, redo_list, redo_count);
+    return hipGetLastError();
 }
 
 hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t count_imm, uint32_t* cursor,
