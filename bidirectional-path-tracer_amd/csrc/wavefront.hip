@@ -646,11 +646,12 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                 if (STATS && redo) n_redo++;
 #endif
                 wb.hit_tri[slot] = redo ? kHitRedo : h.tri;      // position in the reference's leaf order (k_shade turns it into the triangle id)
-                // an exact tie: the ray goes on the list of k_redo, which traces it in the reference's own order
-                if (redo) redo_list[atomicAdd(redo_count, 1u)] = slot;
+                // an exact tie: the ray goes on the list of k_redo, which traces it in the reference's own order; the
+                // distance found here (if any) tells that walk where to look
+                if (redo) { redo_list[atomicAdd(redo_count, 1u)] = slot; wb.hit[slot] = (h.tri >= 0) ? closest : kInf; }
                 // the barycentric coordinates of the hit are not kept: nothing on this path reads them (the
                 // reference's hit_record carries u, v for textures, and every texture here is a solid colour)
-                if (!redo && h.tri >= 0) wb.hit[slot] = closest;
+                else if (h.tri >= 0) wb.hit[slot] = closest;
             }
             has = false;
         }
@@ -808,15 +809,28 @@ __global__ __launch_bounds__(kBlock) void k_redo(SceneDev sc, WfBuffers wb, cons
         const V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
         const V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
         const double tmax = wb.tmax ? wb.tmax[slot] : kInf;
-        int32_t pos;
+        // First with the interval cut off just behind the distance the traversal kernel found.  The reference's walk
+        // and this one visit the same nodes in the same order and accept the same triangles up to that distance (a box
+        // that only the shorter interval misses starts behind it, and so does everything inside), so a hit found this way
+        // IS the reference's; the walk over the unordered median-split tree, which otherwise wanders through
+        // everything the ray's line meets, stays near the hit.  Nothing found (the triangle the kernel saw is one the
+        // reference does not reach): once more with the interval as it was.
+        const double hint = wb.hit[slot];
+        // (distances that tie lie within 2^-19 of each other; a hit distance is good to ~1e-6 of itself even for a ray
+        // that meets its triangle at the reference's smallest accepted determinant)
+        const double bound = hint * 1.0009765625;                          // 1 + 2^-10
+        int32_t pos = -1;
         double t = 0.0;
-        if (INSTANCED) {
-            CxHit rh;
-            pos = redo_closest_instanced(sc, o, d, 0.001, tmax, rh);
-            t = rh.t;
-        } else {
-            const int32_t tri = redo_closest(sc, o, d, tmax, t);
-            pos = tri < 0 ? -1 : (int32_t)sc.tri_pos[tri];
+        for (int pass = (bound < tmax) ? 0 : 1; pass < 2 && pos < 0; pass++) {
+            const double upto = pass == 0 ? bound : tmax;
+            if (INSTANCED) {
+                CxHit rh;
+                pos = redo_closest_instanced(sc, o, d, 0.001, upto, rh);
+                t = rh.t;
+            } else {
+                const int32_t tri = redo_closest(sc, o, d, upto, t);
+                pos = tri < 0 ? -1 : (int32_t)sc.tri_pos[tri];
+            }
         }
         wb.hit_tri[slot] = pos;
         if (pos >= 0) wb.hit[slot] = t;
