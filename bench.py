@@ -201,19 +201,8 @@ def run_cpu_baseline(seed, seconds, flat):
         return ("%d pixels of a %dx%d lattice over the %dx%d frame at the full %d spp / depth %d, one single-threaded "
                 "%s process per core for <= %.0f s; g++ -O2 -ffp-contract=off" % (total_px, nx, ny, W, H, spp_used, depth, what, secs))
 
-    composite = hasattr(flat, "objects")       # (instances: only the reference's own classes can time those, the restatement has none)
-    if composite and not os.path.exists(REF_HARNESS):
-        os.unlink(scene_path)
-        return {"value": None, "unit": "Msamples/s", "cores": cores, "kind": "reference",
-                "sample": "not measured: the reference harness is not built here and the CPU restatement does not cover scenes with instances"}
     try:
         port_secs = seconds if not os.path.exists(REF_HARNESS) else max(5.0, seconds / 2)
-        if composite:
-            rate, total_px, spp_used = run(lambda mine, secs: [REF_HARNESS, scene_path, "bench", str(seed), str(secs), mine], seconds)
-            out = {"value": rate, "unit": "Msamples/s", "cores": cores, "kind": "reference",
-                   "sample": sample_text(total_px, spp_used, seconds, "reference-harness (the reference's headers and object classes, scene build excluded)")}
-            out.update(host)
-            return out
         rate, total_px, spp_used = run(lambda mine, secs: [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-scene", scene_path,
                                                            "--seed", str(seed), "--cpu-seconds", str(secs), "--cpu-pixels", mine], port_secs)
         port = {"value": rate, "unit": "Msamples/s", "cores": cores, "kind": "port",
@@ -403,19 +392,7 @@ def extra_leg(ctx, name, seed, steps, stream, parity_pixels):
     out = {"workload": WORKLOADS[name][3], "triangles": flat.n_triangles, "objects": len(getattr(flat, "objects", [])), "value": W * H * spp_used * depth * steps / elapsed / 1e6,
            "unit": "Msamples/s", "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3, "scene_build_s": build_s,
            "paths_per_s": W * H * spp_used * steps / elapsed}
-    if parity_pixels and hasattr(flat, "objects"):
-        # (the CPU restatement does not cover composite scenes: the pipeline's pixels against the single kernel, which
-        # walks the reference's own two-level tree in the reference's order; both are pinned by reference-made fixtures)
-        import numpy as np
-        host = fb.cpu().numpy()
-        same = 0
-        for a in range(parity_pixels):
-            i, j = int((a + 0.5) * W / parity_pixels), int((a * 7 % parity_pixels + 0.5) * H / parity_pixels)
-            one = scene.render(cam, seed=seed, rect=(i, j, i + 1, j + 1), megakernel=True)
-            same += int((one[j, i].view(np.uint64) == host[j, i].view(np.uint64)).all())
-        out["parity_single_kernel"] = {"against": "single-kernel path of the library (reference-order walk over the two-level tree)",
-                                       "pixels_checked": parity_pixels, "pixels_bit_identical": same}
-    elif parity_pixels:
+    if parity_pixels:
         out["parity"] = oracle_parity(flat, cam, fb, seed, [(int((a + 0.5) * W / parity_pixels), int((a * 7 % parity_pixels + 0.5) * H / parity_pixels))
                                                             for a in range(parity_pixels)])
     scene.close()

@@ -136,7 +136,26 @@ def flat_scene_from_bytes(blob: bytes) -> FlatScene:
     c = struct.unpack_from("<16d4i", blob, off)
     s.camera = Camera(lookfrom=c[0:3], lookat=c[3:6], vup=c[6:9], vfov=c[9], aspect_ratio=c[10], focus_dist=c[11],
                       defocus_angle=c[12], background=c[13:16], image_width=c[16], samples_per_pixel=c[17], max_depth=c[18])
-    return s
+    off += 16 * 8 + 4 * 4
+    if blob[off:off + 8] != b"BDPTEXT1":
+        return s
+    # trailing block of a composite scene (CompositeScene.to_bytes); the bytes of image textures are not in the file
+    n_tex, n_obj, _, _ = struct.unpack_from("<4I", blob, off + 8)
+    off += 24
+    cs = CompositeScene(materials=s.materials, vertices=s.vertices, tri_material=s.tri_material, lights=s.lights, camera=s.camera)
+    moff = 24
+    for m in cs.materials:
+        m.texture = struct.unpack_from("<2i", blob, moff)[1] - 1
+        moff += 48
+    for _ in range(n_tex):
+        t, even, odd, _w, _h, _pad, r, g, b, scale = struct.unpack_from("<6i4d", blob, off)
+        cs.textures.append(Texture(t, (r, g, b), scale, even, odd))
+        off += 56
+    for _ in range(n_obj):
+        first, n, flags, phase, deg, ox, oy, oz, density = struct.unpack_from("<3Ii5d", blob, off)
+        cs.objects.append(SceneObject(first, n, flags, deg, (ox, oy, oz), density, phase))
+        off += 56
+    return cs
 
 
 def _add(a, b):

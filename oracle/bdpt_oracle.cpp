@@ -124,9 +124,27 @@ struct Tri {                              // src/objects/primatives/triangle.h:2
     int32_t mat;
 };
 
-struct Mat { int32_t type; V3 rgb; double fuzz; double ior; };
+struct Mat { int32_t type; V3 rgb; double fuzz; double ior; int32_t tex; };   // tex >= 0: a texture replaces rgb (material.h:45,135,152)
 
-struct Node { Box box; int32_t left, right; };   // child >= 0: node index; < 0: ~triangle index
+// child >= 0: node index; < 0: ~code of a leaf hittable, code < #triangles: that triangle, otherwise the object
+// code - #triangles of a composite scene
+struct Node { Box box; int32_t left, right; };
+
+// src/materials/textures/texture.h:14-87
+struct Texture { int32_t type; V3 rgb; double scale; int32_t even, odd, perlin, width, height; size_t bytes; };
+// what a perlin object holds (perlin.h:53-57)
+struct Perlin { V3 randvec[256]; int perm_x[256], perm_y[256], perm_z[256]; };
+// One object of a composite world's list: translate(rotate_y(bvh_node(mesh))), optionally the boundary of a
+// constant_medium (src/objects/hittable.h:46-157, src/materials/volumes/constant_medium.h)
+struct Object {
+    uint32_t first, count, flags;        // flags: 1 rotate_y, 2 translate, 4 constant_medium
+    int32_t phase;                       // the medium's isotropic material
+    double sin_theta, cos_theta;
+    V3 offset;
+    double neg_inv_density;
+    int32_t root;                        // root of the mesh's own bvh_node tree
+    Box bbox;                            // bounding_box() of the outermost wrapper
+};
 
 struct Stats {                            // src/core/stats.h:8-16 (+ three extra counters)
     uint64_t rays_traced, aabb_tests, aabb_hits, bvh_node_visits, triangle_tests, triangle_hits, bvh_nodes_built;
@@ -135,7 +153,7 @@ struct Stats {                            // src/core/stats.h:8-16 (+ three extr
 
 struct Ray { V3 o, d; };
 
-struct Hit {                              // src/objects/hittable.h:10-27 (+ triangle id)
+struct Hit {                              // src/objects/hittable.h:10-27 (+ triangle id; inside the medium k: -(k + 2))
     V3 p, normal;
     int32_t mat, tri;
     double t, u, v;
@@ -199,20 +217,29 @@ struct oracle_scene {
     std::vector<Tri> tris;
     std::vector<Mat> mats;
     std::vector<uint32_t> lights;        // the `lights` collection: world triangle ids, in order
-    std::vector<Node> nodes;             // pre-order; nodes[0] is the root
+    std::vector<Node> nodes;             // every tree in pre-order; nodes[root] is the root of the world's tree
     uint64_t nodes_built = 0;
+    int32_t root = 0;
+    // composite scenes only
+    bool composite = false;
+    std::vector<Texture> textures;
+    std::vector<Perlin> perlins;
+    std::vector<uint8_t> image_bytes;
+    std::vector<Object> objects;
+    std::vector<uint32_t> loose;         // triangles that are entries of the world's list themselves
 };
 
 namespace {
 
 // src/acceleration/bvh.h:20-48
-int build_node(oracle_scene& s, std::vector<uint32_t>& objects, size_t start, size_t end) {
+// `boxes[code]`: bounding_box() of the leaf hittable with that code
+int build_node(oracle_scene& s, const std::vector<Box>& boxes, std::vector<uint32_t>& objects, size_t start, size_t end) {
     s.nodes_built++;
     int idx = (int)s.nodes.size();
     s.nodes.push_back(Node());
 
     Box bbox = box_empty();
-    for (size_t i = start; i < end; i++) bbox = box_merge(bbox, s.tris[objects[i]].bbox);
+    for (size_t i = start; i < end; i++) bbox = box_merge(bbox, boxes[objects[i]]);
 
     int axis = longest_axis(bbox);
     size_t span = end - start;
@@ -223,14 +250,13 @@ int build_node(oracle_scene& s, std::vector<uint32_t>& objects, size_t start, si
         left = ~(int32_t)objects[start];
         right = ~(int32_t)objects[start + 1];
     } else {
-        const std::vector<Tri>& tris = s.tris;
-        // bvh.h:68-74: strict < on the (unpadded) triangle boxes' minimum along `axis`; same
+        // bvh.h:68-74: strict < on the (unpadded) boxes' minimum along `axis`; same
         // libstdc++ std::sort call as the reference, so equal keys end up in the same order.
         std::sort(objects.begin() + start, objects.begin() + end,
-                  [&tris, axis](uint32_t a, uint32_t b) { return tris[a].bbox.mn[axis] < tris[b].bbox.mn[axis]; });
+                  [&boxes, axis](uint32_t a, uint32_t b) { return boxes[a].mn[axis] < boxes[b].mn[axis]; });
         size_t mid = start + span / 2;
-        left = build_node(s, objects, start, mid);
-        right = build_node(s, objects, mid, end);
+        left = build_node(s, boxes, objects, start, mid);
+        right = build_node(s, boxes, objects, mid, end);
     }
     s.nodes[idx].box = bbox;
     s.nodes[idx].left = left;
@@ -240,10 +266,12 @@ int build_node(oracle_scene& s, std::vector<uint32_t>& objects, size_t start, si
 
 void finish_scene(oracle_scene& s) {
     std::vector<uint32_t> objects(s.tris.size());
-    for (uint32_t i = 0; i < objects.size(); i++) objects[i] = i;   // triangle.h:191-197
+    std::vector<Box> boxes(s.tris.size());
+    for (uint32_t i = 0; i < objects.size(); i++) { objects[i] = i; boxes[i] = s.tris[i].bbox; }   // triangle.h:191-197
     s.nodes.clear();
     s.nodes_built = 0;
-    if (!objects.empty()) build_node(s, objects, 0, objects.size());
+    s.root = 0;
+    if (!objects.empty()) build_node(s, boxes, objects, 0, objects.size());
 }
 
 // src/acceleration/aabb.h:41-66
@@ -295,31 +323,166 @@ inline bool tri_hit(const oracle_scene& s, int32_t id, const Ray& r, double tmin
     return true;
 }
 
+bool node_hit(const oracle_scene& s, int32_t idx, const Ray& r, double tmin, double tmax, Hit& rec, Stats& st, Rng* rng);
+
+// hit() of object k of a composite world's list.  `rng`: the stream constant_medium::hit draws from.
+bool object_hit(const oracle_scene& s, int32_t k, const Ray& r, double tmin, double tmax, Hit& rec, Stats& st, Rng* rng) {
+    const Object& ob = s.objects[k];
+    // boundary->hit(...) through translate::hit (hittable.h:54-66) and rotate_y::hit (:110-148)
+    auto boundary_hit = [&](double lo, double hi, Hit& out) {
+        Ray q = r;
+        if (ob.flags & 2u) q.o = sub(q.o, ob.offset);
+        if (ob.flags & 1u) {
+            const double c = ob.cos_theta, sn = ob.sin_theta;
+            q.o = mk((c * q.o.x) - (sn * q.o.z), q.o.y, (sn * q.o.x) + (c * q.o.z));
+            q.d = mk((c * q.d.x) - (sn * q.d.z), q.d.y, (sn * q.d.x) + (c * q.d.z));
+        }
+        if (!node_hit(s, ob.root, q, lo, hi, out, st, rng)) return false;
+        if (ob.flags & 1u) {
+            const double c = ob.cos_theta, sn = ob.sin_theta;
+            out.p = mk((c * out.p.x) + (sn * out.p.z), out.p.y, (-sn * out.p.x) + (c * out.p.z));
+            out.normal = mk((c * out.normal.x) + (sn * out.normal.z), out.normal.y, (-sn * out.normal.x) + (c * out.normal.z));
+        }
+        if (ob.flags & 2u) out.p = add(out.p, ob.offset);
+        return true;
+    };
+    if (!(ob.flags & 4u)) return boundary_hit(tmin, tmax, rec);
+    // constant_medium::hit, constant_medium.h:20-53
+    Hit rec1, rec2;
+    if (!boundary_hit(-kInfinity, kInfinity, rec1)) return false;
+    if (!boundary_hit(rec1.t + 0.0001, kInfinity, rec2)) return false;
+    if (rec1.t < tmin) rec1.t = tmin;
+    if (rec2.t > tmax) rec2.t = tmax;
+    if (rec1.t >= rec2.t) return false;
+    if (rec1.t < 0) rec1.t = 0;
+    double ray_length = len(r.d);
+    double distance_inside_boundary = (rec2.t - rec1.t) * ray_length;
+    double hit_distance = ob.neg_inv_density * oracle_log(rng->next());
+    if (hit_distance > distance_inside_boundary) return false;
+    rec.t = rec1.t + hit_distance / ray_length;
+    rec.p = add(r.o, scl(rec.t, r.d));
+    rec.normal = mk(1, 0, 0);
+    rec.front_face = true;
+    rec.mat = ob.phase;
+    rec.tri = -(k + 2);
+    rec.u = 0; rec.v = 0;                 // (the reference leaves them unset; nothing a medium can carry reads them)
+    return true;
+}
+
+inline bool leaf_hit(const oracle_scene& s, int32_t code, const Ray& r, double tmin, double tmax, Hit& rec, Stats& st, Rng* rng) {
+    if ((size_t)code < s.tris.size()) return tri_hit(s, code, r, tmin, tmax, rec, st);
+    return object_hit(s, code - (int32_t)s.tris.size(), r, tmin, tmax, rec, st, rng);
+}
+
 // src/acceleration/bvh.h:50-59
-bool node_hit(const oracle_scene& s, int32_t idx, const Ray& r, double tmin, double tmax, Hit& rec, Stats& st) {
+bool node_hit(const oracle_scene& s, int32_t idx, const Ray& r, double tmin, double tmax, Hit& rec, Stats& st, Rng* rng) {
     st.bvh_node_visits++;
     const Node& n = s.nodes[idx];
     if (!box_hit(n.box, r, tmin, tmax, st)) return false;
-    bool hit_left = n.left >= 0 ? node_hit(s, n.left, r, tmin, tmax, rec, st)
-                                : tri_hit(s, ~n.left, r, tmin, tmax, rec, st);
+    bool hit_left = n.left >= 0 ? node_hit(s, n.left, r, tmin, tmax, rec, st, rng)
+                                : leaf_hit(s, ~n.left, r, tmin, tmax, rec, st, rng);
     double rmax = hit_left ? rec.t : tmax;
-    bool hit_right = n.right >= 0 ? node_hit(s, n.right, r, tmin, rmax, rec, st)
-                                  : tri_hit(s, ~n.right, r, tmin, rmax, rec, st);
+    bool hit_right = n.right >= 0 ? node_hit(s, n.right, r, tmin, rmax, rec, st, rng)
+                                  : leaf_hit(s, ~n.right, r, tmin, rmax, rec, st, rng);
     return hit_left || hit_right;
 }
 
-inline bool world_hit(const oracle_scene& s, const Ray& r, double tmin, double tmax, Hit& rec, Stats& st) {
-    return node_hit(s, 0, r, tmin, tmax, rec, st);
+inline bool world_hit(const oracle_scene& s, const Ray& r, double tmin, double tmax, Hit& rec, Stats& st, Rng* rng) {
+    return node_hit(s, s.root, r, tmin, tmax, rec, st, rng);
+}
+
+// ---------------------------------------------------------------- textures (src/materials/textures)
+// perlin::perlin, perlin.h:6-14,59-73: unit_vector(vec3::random(-1, 1)) fills z, y, x in that order (see
+// random_unit_vector above); random_int(0, i) = int(random_double(0, i + 1)), main.h:39-42
+void make_perlin(Perlin& pn, Rng& rng) {
+    for (int i = 0; i < 256; i++) {
+        double pz = rng.next(-1, 1);
+        double py = rng.next(-1, 1);
+        double px = rng.next(-1, 1);
+        pn.randvec[i] = unit(mk(px, py, pz));
+    }
+    int* perms[3] = { pn.perm_x, pn.perm_y, pn.perm_z };
+    for (int* p : perms) {
+        for (int i = 0; i < 256; i++) p[i] = i;
+        for (int i = 255; i > 0; i--) {
+            int target = int(rng.next(0, i + 1));
+            int tmp = p[i];
+            p[i] = p[target];
+            p[target] = tmp;
+        }
+    }
+}
+// perlin::noise + perlin_interp, perlin.h:16-36,75-92
+double perlin_noise(const Perlin& pn, V3 p) {
+    double u = p.x - std::floor(p.x), v = p.y - std::floor(p.y), w = p.z - std::floor(p.z);
+    int i = int(std::floor(p.x)), j = int(std::floor(p.y)), k = int(std::floor(p.z));
+    V3 c[2][2][2];
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++)
+                c[di][dj][dk] = pn.randvec[pn.perm_x[(i + di) & 255] ^ pn.perm_y[(j + dj) & 255] ^ pn.perm_z[(k + dk) & 255]];
+    double uu = u * u * (3 - 2 * u), vv = v * v * (3 - 2 * v), ww = w * w * (3 - 2 * w);
+    double accum = 0.0;
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++)
+            for (int q = 0; q < 2; q++) {
+                V3 weight_v = mk(u - a, v - b, w - q);
+                accum += (a * uu + (1 - a) * (1 - uu)) * (b * vv + (1 - b) * (1 - vv)) * (q * ww + (1 - q) * (1 - ww)) *
+                         dot(c[a][b][q], weight_v);
+            }
+    return accum;
+}
+double perlin_turb(const Perlin& pn, V3 p, int depth) {      // perlin.h:38-50
+    double accum = 0.0;
+    V3 temp_p = p;
+    double weight = 1.0;
+    for (int i = 0; i < depth; i++) {
+        accum += weight * perlin_noise(pn, temp_p);
+        weight *= 0.5;
+        temp_p = mk(temp_p.x * 2, temp_p.y * 2, temp_p.z * 2);
+    }
+    return std::fabs(accum);
+}
+V3 texture_value(const oracle_scene& s, int32_t id, double u, double v, V3 p) {
+    const Texture& t = s.textures[id];
+    switch (t.type) {
+        case 1: {                                            // checker_texture::value, texture.h:36-44 (scale = inv_scale)
+            int xi = int(std::floor(t.scale * p.x)), yi = int(std::floor(t.scale * p.y)), zi = int(std::floor(t.scale * p.z));
+            bool is_even = (xi + yi + zi) % 2 == 0;
+            return texture_value(s, is_even ? t.even : t.odd, u, v, p);
+        }
+        case 2: {                                            // noise_texture::value, texture.h:80-82
+            double sn, cs;
+            oracle_sincos(t.scale * p.z + 10 * perlin_turb(s.perlins[t.perlin], p, 7), &sn, &cs);
+            return scl(1 + sn, mk(.5, .5, .5));
+        }
+        case 3: {                                            // image_texture::value, texture.h:56-70; rtw_stb_image.h:63-88
+            if (t.height <= 0) return mk(0, 1, 1);
+            u = u < 0 ? 0 : (u > 1 ? 1 : u);
+            v = 1.0 - (v < 0 ? 0 : (v > 1 ? 1 : v));
+            int i = int(u * t.width), j = int(v * t.height);
+            i = i < 0 ? 0 : (i < t.width ? i : t.width - 1);
+            j = j < 0 ? 0 : (j < t.height ? j : t.height - 1);
+            const uint8_t* px = &s.image_bytes[t.bytes + ((size_t)j * t.width + i) * 3];
+            double color_scale = 1.0 / 255.0;
+            return mk(color_scale * px[0], color_scale * px[1], color_scale * px[2]);
+        }
+        default: return t.rgb;                               // solid_color
+    }
+}
+inline V3 mat_colour(const oracle_scene& s, const Mat& m, const Hit& rec) {
+    return m.tex >= 0 ? texture_value(s, m.tex, rec.u, rec.v, rec.p) : m.rgb;
 }
 
 // ---------------------------------------------------------------- materials (src/materials/material.h)
-inline V3 mat_emitted(const Mat& m, bool front_face) {       // material.h:20-24,138-143
-    if (m.type == ORACLE_DIFFUSE_LIGHT) return front_face ? m.rgb : mk(0, 0, 0);
+inline V3 mat_emitted(const oracle_scene& s, const Mat& m, const Hit& rec) {       // material.h:20-24,138-143
+    if (m.type == ORACLE_DIFFUSE_LIGHT) return rec.front_face ? mat_colour(s, m, rec) : mk(0, 0, 0);
     return mk(0, 0, 0);
 }
 inline bool mat_is_delta(const Mat& m) { return m.type == ORACLE_METAL || m.type == ORACLE_DIELECTRIC; }  // :85,:118
-inline V3 mat_evaluate_bsdf(const Mat& m) {                  // material.h:35-37,60-63
-    if (m.type == ORACLE_LAMBERTIAN) return divs(m.rgb, kPi);
+inline V3 mat_evaluate_bsdf(const oracle_scene& s, const Mat& m, const Hit& rec) {   // material.h:35-37,60-63,166-168
+    if (m.type == ORACLE_LAMBERTIAN) return divs(mat_colour(s, m, rec), kPi);
+    if (m.type == ORACLE_ISOTROPIC) return divs(mat_colour(s, m, rec), 4 * kPi);
     return mk(0, 0, 0);
 }
 
@@ -348,7 +511,7 @@ void trace_path(const oracle_scene& s, const Camera& cam, Ray current, int depth
     for (int bounce = 0; bounce < depth; ++bounce) {
         st.rays_traced++;
         Hit rec;
-        if (!world_hit(s, current, 0.001, kInfinity, rec, st)) {
+        if (!world_hit(s, current, 0.001, kInfinity, rec, st, &rng)) {
             if (background_contrib) *background_contrib = add(*background_contrib, mulv(throughput, cam.background));
             break;
         }
@@ -357,7 +520,7 @@ void trace_path(const oracle_scene& s, const Camera& cam, Ray current, int depth
         vertex.rec = rec;
         vertex.throughput = throughput;
         vertex.wi = unit(neg(current.d));
-        vertex.emission = mat_emitted(m, rec.front_face);
+        vertex.emission = mat_emitted(s, m, rec);
         vertex.delta = mat_is_delta(m);
         vertex.is_light = (m.type == ORACLE_DIFFUSE_LIGHT);
         path.push_back(vertex);
@@ -388,6 +551,16 @@ void trace_path(const oracle_scene& s, const Camera& cam, Ray current, int depth
             current.d = direction;
             continue;
         }
+        if (m.type == ORACLE_ISOTROPIC) {                    // material.h:154-164, pdf.h:17-28, camera.h:361-368
+            V3 attenuation = mat_colour(s, m, rec);
+            V3 scattered_dir = random_unit_vector(rng);
+            double pdf_value = 1 / (4 * kPi);
+            double scattering_pdf = 1 / (4 * kPi);
+            throughput = divs(scl(scattering_pdf, mulv(throughput, attenuation)), pdf_value);
+            current.o = rec.p;
+            current.d = scattered_dir;
+            continue;
+        }
         // lambertian: material.h:47-58, pdf.h:32-47, camera.h:361-368
         Onb uvw = make_onb(rec.normal);
         V3 scattered_dir = onb_transform(uvw, random_cosine_direction(rng));
@@ -396,7 +569,7 @@ void trace_path(const oracle_scene& s, const Camera& cam, Ray current, int depth
         if (pdf_value <= 0) break;
         double cos_theta = dot(rec.normal, unit(scattered_dir));
         double scattering_pdf = cos_theta < 0 ? 0 : cos_theta / kPi;
-        throughput = divs(scl(scattering_pdf, mulv(throughput, m.rgb)), pdf_value);
+        throughput = divs(scl(scattering_pdf, mulv(throughput, mat_colour(s, m, rec))), pdf_value);
         current.o = rec.p;
         current.d = scattered_dir;
     }
@@ -435,7 +608,10 @@ bool build_light_path(const oracle_scene& s, const Camera& cam, const std::vecto
     double pdf;
     if (!sample_surface(s, lights, rng, position, normal, mat, pdf)) return false;
 
-    V3 emission = mat_emitted(s.mats[mat], true);
+    Hit light_rec;                                            // camera.h:385-391
+    light_rec.p = position; light_rec.normal = normal; light_rec.mat = mat; light_rec.tri = -1;
+    light_rec.front_face = true; light_rec.t = 0; light_rec.u = 0; light_rec.v = 0;
+    V3 emission = mat_emitted(s, s.mats[mat], light_rec);
     if (len2(emission) <= 0) return false;
 
     PathVertex ev;
@@ -468,7 +644,7 @@ bool build_light_path(const oracle_scene& s, const Camera& cam, const std::vecto
 }
 
 // camera.h:425-438
-bool visible(const oracle_scene& s, V3 a, V3 b, Stats& st) {
+bool visible(const oracle_scene& s, V3 a, V3 b, Stats& st, Rng* rng) {
     V3 dir = sub(b, a);
     double dist = len(dir);
     if (dist <= 0) return false;
@@ -480,11 +656,11 @@ bool visible(const oracle_scene& s, V3 a, V3 b, Stats& st) {
     if (max_t <= 0) return false;
     st.shadow_rays++;
     Hit tmp;
-    return !world_hit(s, shadow, 0.001, max_t, tmp, st);
+    return !world_hit(s, shadow, 0.001, max_t, tmp, st, rng);
 }
 
 // camera.h:440-475
-V3 connect_vertices(const oracle_scene& s, const PathVertex& cam_v, const PathVertex& light_v, Stats& st) {
+V3 connect_vertices(const oracle_scene& s, const PathVertex& cam_v, const PathVertex& light_v, Stats& st, Rng* rng) {
     if (cam_v.delta || light_v.delta) return mk(0, 0, 0);
     st.pairs++;
     V3 dir = sub(light_v.rec.p, cam_v.rec.p);
@@ -494,10 +670,10 @@ V3 connect_vertices(const oracle_scene& s, const PathVertex& cam_v, const PathVe
     double cos_cam = std::fabs(dot(cam_v.rec.normal, dir_unit));
     double cos_light = std::fabs(dot(light_v.rec.normal, neg(dir_unit)));
     if (cos_cam <= 0 || cos_light <= 0) return mk(0, 0, 0);
-    if (!visible(s, cam_v.rec.p, light_v.rec.p, st)) return mk(0, 0, 0);
-    V3 f_cam = mat_evaluate_bsdf(s.mats[cam_v.rec.mat]);
+    if (!visible(s, cam_v.rec.p, light_v.rec.p, st, rng)) return mk(0, 0, 0);
+    V3 f_cam = mat_evaluate_bsdf(s, s.mats[cam_v.rec.mat], cam_v.rec);
     if (len2(f_cam) <= 0) return mk(0, 0, 0);
-    V3 f_light = light_v.is_light ? light_v.emission : mat_evaluate_bsdf(s.mats[light_v.rec.mat]);
+    V3 f_light = light_v.is_light ? light_v.emission : mat_evaluate_bsdf(s, s.mats[light_v.rec.mat], light_v.rec);
     if (len2(f_light) <= 0) return mk(0, 0, 0);
     V3 contrib = mulv(cam_v.throughput, f_cam);
     contrib = mulv(mulv(contrib, light_v.throughput), f_light);
@@ -521,7 +697,7 @@ V3 bidirectional_color(const oracle_scene& s, const Camera& cam, const std::vect
     if (!build_light_path(s, cam, lights, depth, light_path, rng, st)) return result;
 
     for (const PathVertex& cv : camera_path)
-        for (const PathVertex& lv : light_path) result = add(result, connect_vertices(s, cv, lv, st));
+        for (const PathVertex& lv : light_path) result = add(result, connect_vertices(s, cv, lv, st, &rng));
     return result;
 }
 
@@ -565,9 +741,9 @@ V3 path_trace_color(const oracle_scene& s, const Camera& cam, const std::vector<
     st.rays_traced++;
     if (depth <= 0) return mk(0, 0, 0);
     Hit rec;
-    if (!world_hit(s, r, 0.001, kInfinity, rec, st)) return cam.background;
+    if (!world_hit(s, r, 0.001, kInfinity, rec, st, &rng)) return cam.background;
     const Mat& m = s.mats[rec.mat];
-    V3 color_from_emission = mat_emitted(m, rec.front_face);
+    V3 color_from_emission = mat_emitted(s, m, rec);
     if (m.type == ORACLE_DIFFUSE_LIGHT) return color_from_emission;              // scatter() == false
     if (m.type == ORACLE_METAL) {                                                // material.h:73-83
         V3 reflected = reflect(r.d, rec.normal);
@@ -591,20 +767,22 @@ V3 path_trace_color(const oracle_scene& s, const Camera& cam, const std::vector<
         next.o = rec.p; next.d = direction;
         return mulv(mk(1.0, 1.0, 1.0), path_trace_color(s, cam, lights, next, depth - 1, rng, st));
     }
-    // lambertian: mixture of the light pdf and the cosine pdf
+    // lambertian / isotropic: mixture of the light pdf and the material's own pdf (cosine_pdf / sphere_pdf)
+    const bool iso = (m.type == ORACLE_ISOTROPIC);
     Onb uvw = make_onb(rec.normal);
     V3 direction;
     if (rng.next() < 0.5) direction = lights_random(s, lights, rec.p, rng);
-    else direction = onb_transform(uvw, random_cosine_direction(rng));
-    double cosine_theta = dot(unit(direction), uvw.a2);
-    double pdf_value = 0.5 * lights_pdf_value(s, lights, rec.p, direction, st) + 0.5 * std::fmax(0, cosine_theta / kPi);
+    else direction = iso ? random_unit_vector(rng) : onb_transform(uvw, random_cosine_direction(rng));
+    double own = iso ? 1 / (4 * kPi) : std::fmax(0, dot(unit(direction), uvw.a2) / kPi);
+    double pdf_value = 0.5 * lights_pdf_value(s, lights, rec.p, direction, st) + 0.5 * own;
     if (pdf_value <= 0) return color_from_emission;
-    double cos_theta = dot(rec.normal, unit(direction));
-    double scattering_pdf = cos_theta < 0 ? 0 : cos_theta / kPi;
+    double scattering_pdf;
+    if (iso) scattering_pdf = 1 / (4 * kPi);
+    else { double cos_theta = dot(rec.normal, unit(direction)); scattering_pdf = cos_theta < 0 ? 0 : cos_theta / kPi; }
     Ray scattered;
     scattered.o = rec.p; scattered.d = direction;
     V3 sample_color = path_trace_color(s, cam, lights, scattered, depth - 1, rng, st);
-    V3 color_from_scatter = divs(mulv(scl(scattering_pdf, m.rgb), sample_color), pdf_value);
+    V3 color_from_scatter = divs(mulv(scl(scattering_pdf, mat_colour(s, m, rec)), sample_color), pdf_value);
     return add(color_from_emission, color_from_scatter);
 }
 
@@ -652,6 +830,7 @@ void export_stats(const Stats& st, const oracle_scene& s, const Rng& rng, uint64
 // src/main.cpp:67
 const std::vector<uint32_t>& effective_lights(const oracle_scene& s, std::vector<uint32_t>& scratch) {
     if (!s.lights.empty()) return s.lights;
+    if (s.composite) return s.loose;                       // (every triangle that is an entry of the world's list itself)
     scratch.resize(s.tris.size());
     for (uint32_t i = 0; i < scratch.size(); i++) scratch[i] = i;
     return scratch;
@@ -672,6 +851,7 @@ oracle_scene* oracle_scene_create(const double* tv, const int32_t* tri_material,
         m.rgb = mk(mat_params[5 * i], mat_params[5 * i + 1], mat_params[5 * i + 2]);
         m.fuzz = mat_params[5 * i + 3] < 1 ? mat_params[5 * i + 3] : 1;     // material.h:71
         m.ior = mat_params[5 * i + 4];
+        m.tex = -1;
         s->mats.push_back(m);
     }
     for (uint32_t i = 0; i < n_tri; i++) {
@@ -681,6 +861,156 @@ oracle_scene* oracle_scene_create(const double* tv, const int32_t* tri_material,
     s->lights.assign(lights, lights + n_lights);
     finish_scene(*s);
     return s;
+}
+
+static void dfs_leaves(const oracle_scene* s, int32_t c, std::vector<uint32_t>& out);
+
+/* A composite scene (instances, textures, media): the world list a C++ host of the reference would assemble, see
+ * oracle/flat_scene.h.  tex_ints: 6 per texture (type even odd width height pad), tex_doubles: 4 (rgb, scale);
+ * image_bytes: the bytes of all image textures in texture order (what the reference's loader made of the files);
+ * obj_ints: 4 per object (first_triangle n_triangles flags phase_material), obj_doubles: 5 (degrees, offset, density).
+ * The perlin tables of noise texture i are built here as the reference's constructor builds them, on the stream
+ * (0x7065726c696e, i, 0) the reference harness gives that constructor. */
+oracle_scene* oracle_scene_create_composite(const double* tv, const int32_t* tri_material, uint32_t n_tri, const int32_t* mat_type,
+                                            const double* mat_params, const int32_t* mat_tex, uint32_t n_mat,
+                                            const int32_t* tex_ints, const double* tex_doubles, uint32_t n_tex,
+                                            const uint8_t* image_bytes, uint64_t n_image_bytes, const int32_t* obj_ints,
+                                            const double* obj_doubles, uint32_t n_obj, const uint32_t* lights, uint32_t n_lights) {
+    if (n_tri == 0) return nullptr;
+    oracle_scene* s = new oracle_scene();
+    s->composite = true;
+    for (uint32_t i = 0; i < n_mat; i++) {
+        Mat m;
+        m.type = mat_type[i];
+        m.rgb = mk(mat_params[5 * i], mat_params[5 * i + 1], mat_params[5 * i + 2]);
+        m.fuzz = mat_params[5 * i + 3] < 1 ? mat_params[5 * i + 3] : 1;
+        m.ior = mat_params[5 * i + 4];
+        m.tex = mat_tex[i];
+        s->mats.push_back(m);
+    }
+    s->image_bytes.assign(image_bytes, image_bytes + n_image_bytes);
+    size_t at = 0;
+    for (uint32_t i = 0; i < n_tex; i++) {
+        Texture t;
+        t.type = tex_ints[6 * i]; t.even = tex_ints[6 * i + 1]; t.odd = tex_ints[6 * i + 2];
+        t.width = tex_ints[6 * i + 3]; t.height = tex_ints[6 * i + 4];
+        t.rgb = mk(tex_doubles[4 * i], tex_doubles[4 * i + 1], tex_doubles[4 * i + 2]);
+        t.scale = tex_doubles[4 * i + 3];
+        t.perlin = -1; t.bytes = 0;
+        if (t.type == 1) t.scale = 1.0 / t.scale;            // inv_scale, texture.h:31
+        if (t.type == 2) {
+            Rng rng;
+            rng.engine = 0; rng.mt = nullptr; rng.total = 0;
+            rng.st.key = orng_stream_key(0x7065726c696eULL, i, 0);
+            rng.st.counter = 0;
+            Perlin pn;
+            make_perlin(pn, rng);
+            t.perlin = (int32_t)s->perlins.size();
+            s->perlins.push_back(pn);
+        }
+        if (t.type == 3) { t.bytes = at; at += (size_t)(t.width > 0 ? t.width : 0) * (size_t)(t.height > 0 ? t.height : 0) * 3; }
+        s->textures.push_back(t);
+    }
+    for (uint32_t i = 0; i < n_tri; i++) {
+        const double* v = tv + 9 * (size_t)i;
+        s->tris.push_back(make_tri(mk(v[0], v[1], v[2]), mk(v[3], v[4], v[5]), mk(v[6], v[7], v[8]), tri_material[i]));
+    }
+    s->lights.assign(lights, lights + n_lights);
+
+    // leaf codes: triangles 0 .. n_tri - 1, then the objects
+    std::vector<Box> boxes(n_tri + n_obj);
+    for (uint32_t i = 0; i < n_tri; i++) boxes[i] = s->tris[i].bbox;
+    std::vector<int> owner(n_tri, -1);
+    std::vector<int32_t> mesh_root(n_tri, -1);               // by first triangle: the mesh is built once, objects share it
+    s->objects.resize(n_obj);
+    for (uint32_t k = 0; k < n_obj; k++) {
+        Object& ob = s->objects[k];
+        ob.first = (uint32_t)obj_ints[4 * k]; ob.count = (uint32_t)obj_ints[4 * k + 1];
+        ob.flags = (uint32_t)obj_ints[4 * k + 2]; ob.phase = obj_ints[4 * k + 3];
+        const double degrees = obj_doubles[5 * k];
+        ob.offset = mk(obj_doubles[5 * k + 1], obj_doubles[5 * k + 2], obj_doubles[5 * k + 3]);
+        ob.neg_inv_density = (ob.flags & 4u) ? -1 / obj_doubles[5 * k + 4] : 0.0;     // constant_medium.h:11
+        oracle_sincos(degrees * kPi / 180.0, &ob.sin_theta, &ob.cos_theta);          // hittable.h:79-81, main.h:24-26
+        for (uint32_t i = 0; i < ob.count; i++) owner[ob.first + i] = (int)k;
+        if (mesh_root[ob.first] < 0) {                       // make_shared<bvh_node>(mesh)
+            std::vector<uint32_t> items(ob.count);
+            for (uint32_t i = 0; i < ob.count; i++) items[i] = ob.first + i;
+            mesh_root[ob.first] = build_node(*s, boxes, items, 0, items.size());
+        }
+        ob.root = mesh_root[ob.first];
+        Box b = s->nodes[ob.root].box;
+        if (ob.flags & 1u) {                                 // rotate_y::rotate_y, hittable.h:82-107
+            double mn[3] = { kInfinity, kInfinity, kInfinity }, mx[3] = { -kInfinity, -kInfinity, -kInfinity };
+            for (int i = 0; i < 2; i++)
+                for (int j = 0; j < 2; j++)
+                    for (int q = 0; q < 2; q++) {
+                        double x = i * b.mx[0] + (1 - i) * b.mn[0];
+                        double y = j * b.mx[1] + (1 - j) * b.mn[1];
+                        double z = q * b.mx[2] + (1 - q) * b.mn[2];
+                        double newx = ob.cos_theta * x + ob.sin_theta * z;
+                        double newz = -ob.sin_theta * x + ob.cos_theta * z;
+                        double tester[3] = { newx, y, newz };
+                        for (int c = 0; c < 3; c++) {
+                            mn[c] = std::fmin(mn[c], tester[c]);
+                            mx[c] = std::fmax(mx[c], tester[c]);
+                        }
+                    }
+            for (int c = 0; c < 3; c++) {                    // aabb(point, point), aabb.h:18-25
+                if (mn[c] <= mx[c]) { b.mn[c] = mn[c]; b.mx[c] = mx[c]; }
+                else { b.mn[c] = mx[c]; b.mx[c] = mn[c]; }
+            }
+        }
+        if (ob.flags & 2u) {                                 // bbox + offset, aabb.h:95-97 (interval constructor: pads)
+            const double off[3] = { ob.offset.x, ob.offset.y, ob.offset.z };
+            for (int c = 0; c < 3; c++) { b.mn[c] = b.mn[c] + off[c]; b.mx[c] = b.mx[c] + off[c]; pad_axis(b.mn[c], b.mx[c]); }
+        }
+        ob.bbox = b;
+        boxes[n_tri + k] = b;
+    }
+    // the world's list: triangles of no object, and every object at the place of its first triangle (objects that
+    // share a mesh in the order of their indices); bvh_node(list), src/main.cpp:66
+    std::vector<uint32_t> items;
+    for (uint32_t i = 0; i < n_tri;) {
+        if (owner[i] < 0) { items.push_back(i); s->loose.push_back(i); i++; continue; }
+        uint32_t span = 0;
+        for (uint32_t k = 0; k < n_obj; k++)
+            if (s->objects[k].first == i) { items.push_back(n_tri + k); span = s->objects[k].count; }
+        i += span;
+    }
+    s->root = build_node(*s, boxes, items, 0, items.size());
+    return s;
+}
+
+/* leaves of the world's tree in visiting order: triangle id, or -(object + 2) */
+uint32_t oracle_world_leaves(const oracle_scene* s, int32_t* out, uint32_t capacity) {
+    std::vector<uint32_t> v;
+    dfs_leaves(s, s->root, v);
+    const uint32_t n_tri = (uint32_t)s->tris.size();
+    for (uint32_t i = 0; i < v.size() && i < capacity; i++) out[i] = v[i] < n_tri ? (int32_t)v[i] : -((int32_t)(v[i] - n_tri) + 2);
+    return (uint32_t)v.size();
+}
+static void world_boxes(const oracle_scene* s, int32_t c, std::vector<double>& out) {
+    if (c < 0) return;
+    for (int k = 0; k < 3; k++) { out.push_back(s->nodes[c].box.mn[k]); out.push_back(s->nodes[c].box.mx[k]); }
+    world_boxes(s, s->nodes[c].left, out);
+    world_boxes(s, s->nodes[c].right, out);
+}
+/* boxes of the world tree's nodes in pre-order (6 doubles each); returns the number of nodes */
+uint32_t oracle_world_boxes(const oracle_scene* s, double* out, uint32_t capacity_nodes) {
+    std::vector<double> v;
+    world_boxes(s, s->root, v);
+    for (size_t i = 0; i < v.size() && i < (size_t)capacity_nodes * 6; i++) out[i] = v[i];
+    return (uint32_t)(v.size() / 6);
+}
+/* perlin tables of the noise textures in texture order: 768 doubles (randvec) + 768 doubles (perm_x, perm_y, perm_z) each */
+uint32_t oracle_perlin_tables(const oracle_scene* s, double* out) {
+    for (size_t n = 0; n < s->perlins.size(); n++) {
+        double* o = out + 1536 * n;
+        const Perlin& pn = s->perlins[n];
+        for (int k = 0; k < 256; k++) { o[3 * k] = pn.randvec[k].x; o[3 * k + 1] = pn.randvec[k].y; o[3 * k + 2] = pn.randvec[k].z; }
+        for (int k = 0; k < 256; k++) { o[768 + k] = pn.perm_x[k]; o[1024 + k] = pn.perm_y[k]; o[1280 + k] = pn.perm_z[k]; }
+    }
+    return (uint32_t)s->perlins.size();
 }
 
 oracle_scene* oracle_scene_load(const char* path, double* cam_pub, int32_t* cam_ints) {
@@ -719,7 +1049,7 @@ static void dfs_leaves(const oracle_scene* s, int32_t c, std::vector<uint32_t>& 
 
 uint32_t oracle_bvh_dfs_leaves(const oracle_scene* s, uint32_t* out, uint32_t capacity) {
     std::vector<uint32_t> v;
-    dfs_leaves(s, 0, v);
+    dfs_leaves(s, s->root, v);
     for (uint32_t i = 0; i < v.size() && i < capacity; i++) out[i] = v[i];
     return (uint32_t)v.size();
 }
@@ -787,8 +1117,13 @@ void oracle_trace_closest(const oracle_scene* s, const double* rays, uint64_t n,
         ray.o = mk(r[0], r[1], r[2]);
         ray.d = mk(r[3], r[4], r[5]);
         Hit rec;
+        rec.u = 0; rec.v = 0;
+        Rng rng;                                            // query i draws from stream (seed 0, pixel i, sample 0): media
+        rng.engine = 0; rng.mt = nullptr; rng.total = 0;
+        rng.st.key = orng_stream_key(0, i, 0);
+        rng.st.counter = 0;
         double* o = out + 11 * i;
-        if (!world_hit(*s, ray, r[6], r[7], rec, st)) {
+        if (!world_hit(*s, ray, r[6], r[7], rec, st, &rng)) {
             o[0] = -1.0;
             for (int k = 1; k < 11; k++) o[k] = 0.0;
         } else {
@@ -833,7 +1168,11 @@ void oracle_visible(const oracle_scene* s, const double* pairs, uint64_t n, doub
     memset(&st, 0, sizeof st);
     for (uint64_t i = 0; i < n; i++) {
         const double* p = pairs + 6 * i;
-        out[i] = visible(*s, mk(p[0], p[1], p[2]), mk(p[3], p[4], p[5]), st) ? 1.0 : 0.0;
+        Rng rng;
+        rng.engine = 0; rng.mt = nullptr; rng.total = 0;
+        rng.st.key = orng_stream_key(0, i, 0);
+        rng.st.counter = 0;
+        out[i] = visible(*s, mk(p[0], p[1], p[2]), mk(p[3], p[4], p[5]), st, &rng) ? 1.0 : 0.0;
     }
 }
 

@@ -19,7 +19,7 @@ extern "C" {
 typedef struct oracle_scene oracle_scene;
 
 /* material types */
-enum { ORACLE_LAMBERTIAN = 0, ORACLE_METAL = 1, ORACLE_DIELECTRIC = 2, ORACLE_DIFFUSE_LIGHT = 3 };
+enum { ORACLE_LAMBERTIAN = 0, ORACLE_METAL = 1, ORACLE_DIELECTRIC = 2, ORACLE_DIFFUSE_LIGHT = 3, ORACLE_ISOTROPIC = 4 };
 
 /* tri_vertices: n_tri * 9 doubles (v0 v1 v2); mat_params: n_mat * 5 doubles (r g b fuzz ior);
  * lights: indices of the world triangles that make up the `lights` collection
@@ -27,6 +27,17 @@ enum { ORACLE_LAMBERTIAN = 0, ORACLE_METAL = 1, ORACLE_DIELECTRIC = 2, ORACLE_DI
 oracle_scene* oracle_scene_create(const double* tri_vertices, const int32_t* tri_material, uint32_t n_tri,
                                   const int32_t* mat_type, const double* mat_params, uint32_t n_mat,
                                   const uint32_t* lights, uint32_t n_lights);
+/* A composite scene - translate / rotate_y instances over meshes of their own, checker / noise / image textures,
+ * constant_medium with its isotropic phase function (src/objects/hittable.h:46-157, src/materials/textures/texture.h,
+ * perlin.h, src/materials/volumes/constant_medium.h, src/materials/material.h:149-172); arguments in bdpt_oracle.cpp. */
+oracle_scene* oracle_scene_create_composite(const double* tri_vertices, const int32_t* tri_material, uint32_t n_tri,
+                                            const int32_t* mat_type, const double* mat_params, const int32_t* mat_tex, uint32_t n_mat,
+                                            const int32_t* tex_ints, const double* tex_doubles, uint32_t n_tex,
+                                            const uint8_t* image_bytes, uint64_t n_image_bytes, const int32_t* obj_ints,
+                                            const double* obj_doubles, uint32_t n_obj, const uint32_t* lights, uint32_t n_lights);
+uint32_t oracle_world_leaves(const oracle_scene* s, int32_t* out, uint32_t capacity);
+uint32_t oracle_world_boxes(const oracle_scene* s, double* out, uint32_t capacity_nodes);
+uint32_t oracle_perlin_tables(const oracle_scene* s, double* out);
 oracle_scene* oracle_scene_load(const char* flat_scene_path, double* camera_public_out /* 17 doubles */,
                                 int32_t* camera_ints_out /* image_width, samples_per_pixel, max_depth */);
 void oracle_scene_destroy(oracle_scene* s);

@@ -40,10 +40,60 @@ class OracleScene:
         self._li = flat.light_array()
         if len(self._li) == 0:
             self._li = np.zeros(1, dtype=np.uint32)
-        self.h = lib.oracle_scene_create(self._v, self._tm, flat.n_triangles, self._mt, self._mp, len(flat.materials),
-                                         self._li, len(flat.lights))
+        if hasattr(flat, "objects"):
+            self.h = self._create_composite(lib, flat)
+        else:
+            self.h = lib.oracle_scene_create(self._v, self._tm, flat.n_triangles, self._mt, self._mp, len(flat.materials),
+                                             self._li, len(flat.lights))
         if not self.h:
             raise RuntimeError("oracle_scene_create failed")
+
+    def _create_composite(self, lib, flat):
+        """A composite scene (instances, textures, media).  The bytes of image textures are input (flat.image_bytes: what
+        the reference's loader made of the files); the perlin tables are built by the oracle itself."""
+        tex_i = np.zeros((max(len(flat.textures), 1), 6), dtype=np.int32)
+        tex_d = np.zeros((max(len(flat.textures), 1), 4))
+        images = []
+        k = 0
+        for i, t in enumerate(flat.textures):
+            w = h = 0
+            if t.type == 3:
+                img = np.ascontiguousarray(flat.image_bytes[k], dtype=np.uint8)
+                k += 1
+                h, w = img.shape[0], img.shape[1]
+                images.append(img.reshape(-1))
+            tex_i[i] = [t.type, t.even, t.odd, w, h, 0]
+            tex_d[i] = [t.rgb[0], t.rgb[1], t.rgb[2], t.scale]
+        img_all = np.concatenate(images) if images else np.zeros(1, dtype=np.uint8)
+        obj_i = np.zeros((max(len(flat.objects), 1), 4), dtype=np.int32)
+        obj_d = np.zeros((max(len(flat.objects), 1), 5))
+        for i, ob in enumerate(flat.objects):
+            obj_i[i] = [ob.first_triangle, ob.n_triangles, ob.flags, ob.phase_material]
+            obj_d[i] = [ob.rotate_y_degrees, ob.offset[0], ob.offset[1], ob.offset[2], ob.density]
+        mat_tex = np.array([m.texture for m in flat.materials], dtype=np.int32)
+        return lib.oracle_scene_create_composite(self._v, self._tm, flat.n_triangles, self._mt, self._mp, mat_tex,
+                                                 len(flat.materials), tex_i, tex_d, len(flat.textures), img_all,
+                                                 sum(len(a) for a in images), obj_i, obj_d, len(flat.objects), self._li,
+                                                 len(flat.lights))
+
+    def world_leaves(self):
+        """Leaves of the world's tree in visiting order: triangle id, or -(object + 2)."""
+        cap = self.flat.n_triangles + len(getattr(self.flat, "objects", [])) + 4
+        out = np.zeros(cap, dtype=np.int32)
+        n = self.lib.oracle_world_leaves(self.h, out, cap)
+        return out[:n].copy()
+
+    def world_boxes(self):
+        cap = 2 * (self.flat.n_triangles + len(getattr(self.flat, "objects", []))) + 4
+        out = np.zeros((cap, 6))
+        n = self.lib.oracle_world_boxes(self.h, out, cap)
+        return out[:n].copy()
+
+    def perlin_tables(self):
+        n = sum(1 for t in self.flat.textures if t.type == 2)
+        out = np.zeros((max(n, 1), 1536))
+        assert self.lib.oracle_perlin_tables(self.h, out) == n
+        return out[:n]
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -114,6 +164,15 @@ class Oracle:
         lib = C.CDLL(LIB)
         lib.oracle_scene_create.restype = C.c_void_p
         lib.oracle_scene_create.argtypes = [_d, _i32, C.c_uint32, _i32, _d, C.c_uint32, _u32, C.c_uint32]
+        lib.oracle_scene_create_composite.restype = C.c_void_p
+        lib.oracle_scene_create_composite.argtypes = [_d, _i32, C.c_uint32, _i32, _d, _i32, C.c_uint32, _i32, _d, C.c_uint32,
+                                                      _u8, C.c_uint64, _i32, _d, C.c_uint32, _u32, C.c_uint32]
+        lib.oracle_world_leaves.restype = C.c_uint32
+        lib.oracle_world_leaves.argtypes = [C.c_void_p, _i32, C.c_uint32]
+        lib.oracle_world_boxes.restype = C.c_uint32
+        lib.oracle_world_boxes.argtypes = [C.c_void_p, _d, C.c_uint32]
+        lib.oracle_perlin_tables.restype = C.c_uint32
+        lib.oracle_perlin_tables.argtypes = [C.c_void_p, _d]
         lib.oracle_scene_destroy.argtypes = [C.c_void_p]
         lib.oracle_bvh_node_count.restype = C.c_uint32
         lib.oracle_bvh_node_count.argtypes = [C.c_void_p]

@@ -233,6 +233,56 @@ def test_large_instanced_lattice_pipeline_equals_single_kernel(ctx, scenes):
     sc.close()
 
 
+@pytest.mark.parametrize("which", ["smoke", "textures", "instances", "lattice"])
+def test_scenes_without_fixture_match_the_oracle(ctx, scenes, oracle, which):
+    """Other sizes, depths and seeds than the fixtures hold, against the CPU restatement (itself pinned by those
+    fixtures): tree, hit records, visibility, both estimators with their counters.  Noise textures get the tables the
+    oracle's restatement of perlin::perlin builds; the image texture's bytes are given as they are."""
+    flat = {"smoke": lambda: scenes.cornell_smoke(28, 9, 6), "textures": lambda: scenes.cornell_textures(28, 9, 11),
+            "instances": lambda: scenes.cornell_instances(40, 4, 3), "lattice": lambda: scenes.sphere_lattice_instanced(5, 48, 9, 12)}[which]()
+    flat.image_bytes = [np.ascontiguousarray(t.image) for t in flat.textures if t.type == scenes.TEX_IMAGE]
+    osc = oracle.scene(flat)
+    flat.perlin_tables = [t for t in osc.perlin_tables()]
+    sc = ctx.scene(flat)
+    assert np.array_equal(sc.dfs_leaves().astype(np.int32), osc.world_leaves())
+    wb = osc.world_boxes()
+    assert_bit_equal(sc.node_boxes()[:len(wb)], wb, which + ": world tree")
+    cam = capi.camera_initialize(flat.camera)
+    ocam, H, sqrt_spp = oracle.camera_initialize(flat.camera)
+    W, depth, seed = flat.camera.image_width, flat.camera.max_depth, 77
+    ofb, ost, _ = osc.render(ocam, W, sqrt_spp, depth, seed, (0, 0, W, H))
+    fb, st = sc.render(cam, seed=seed, want_stats=True)
+    assert_bit_equal(fb, ofb, which + ": framebuffer")
+    assert_bit_equal(sc.render(cam, seed=seed), ofb, which + ": framebuffer, default path")
+    d = st.as_dict()
+    assert [d["rays_traced"], d["aabb_tests"], d["aabb_hits"], d["bvh_node_visits"], d["triangle_tests"], d["triangle_hits"]] == [int(v) for v in ost[:6]]
+    assert d["rng_draws"] == int(ost[7])
+    ofb, ost = osc.render_unidirectional(ocam, W, sqrt_spp, depth, seed, (0, 0, W, H))
+    fb, st = sc.render(cam, seed=seed, unidirectional=True, want_stats=True)
+    assert_bit_equal(fb, ofb, which + ": unidirectional framebuffer")
+    assert st.as_dict()["rng_draws"] == int(ost[7])
+    # rays from the camera's side through the scene's bounding box, pairs between their hit points
+    v = flat.vertex_array().reshape(-1, 3)
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    if which == "lattice":
+        hi = hi + 3.0 * 4                                  # the instances' offsets
+    rng = np.random.default_rng(11)
+    n = 6000
+    o = rng.uniform(lo - 0.3 * (hi - lo), hi + 0.3 * (hi - lo), (n, 3))
+    tgt = rng.uniform(lo, hi, (n, 3))
+    rays = np.concatenate([o, tgt - o, np.full((n, 1), 0.001), np.full((n, 1), np.inf)], axis=1)
+    hits = sc.trace_closest(rays)
+    ohits, _ = osc.trace_closest(rays)
+    assert np.array_equal(hits[:, 0], ohits[:, 0])
+    found = ohits[:, 0] != -1
+    assert found.sum() > n // 4
+    assert_bit_equal(hits[found][:, [1, 4, 5, 6, 7, 8, 9, 10]], ohits[found][:, [1, 4, 5, 6, 7, 8, 9, 10]], which + ": hit records")
+    pts = ohits[found][:, 5:8]
+    pairs = np.concatenate([pts[rng.integers(0, len(pts), 4000)], pts[rng.integers(0, len(pts), 4000)]], axis=1)
+    assert np.array_equal(sc.visible(pairs), osc.visible(pairs))
+    sc.close()
+
+
 def test_composite_without_objects_equals_plain_scene(ctx, scenes):
     """A composite scene with no object and no texture is the plain triangle soup: the same tables, the same kernels
     (the Cornell box is small enough for the variants that keep the whole scene in LDS), the same bits."""
