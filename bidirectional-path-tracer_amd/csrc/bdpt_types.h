@@ -105,6 +105,21 @@ struct CxObject {
     uint32_t pad;
 };
 
+// src/materials/textures/texture.h
+struct CxTexture {
+    double rgb[3];
+    double scale;                  // noise: scale; checker: inv_scale = 1.0 / scale (texture.h:31)
+    int32_t type;                  // BDPT_TEX_*
+    int32_t a, b;                  // checker: even / odd texture; image: width / height
+    uint32_t data;                 // noise: index of its tables in `perlin`; image: first byte in `image_bytes`
+};
+
+// What a perlin object holds (perlin.h:53-57)
+struct CxPerlin {
+    double randvec[256][3];
+    int32_t perm_x[256], perm_y[256], perm_z[256];
+};
+
 struct SceneDev {
     const GpuNode* nodes;
     const GpuTri* tris;
@@ -138,6 +153,11 @@ struct SceneDev {
     const int32_t* pos_obj;         // the same per entry of `stris`
     const uint32_t* obj_leaf;       // per object: the node of the world's tree that holds it (| bit 31 = ref_nested)
     const uint32_t* obj_pos0;       // per object: position in `stris` of the first triangle of its mesh
+    // Scenes with textured materials on the pipeline (they run the kernels of scenes with instances): GpuMaterial::pad
+    // of `mats` is then the texture index + 1 of the material, 0 for a solid colour.
+    const CxTexture* tex;           // null: every material is a solid colour
+    const CxPerlin* perlin;
+    const uint8_t* image_bytes;
 };
 
 struct RenderLaunch {

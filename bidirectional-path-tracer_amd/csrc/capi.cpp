@@ -274,6 +274,7 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
     if (!cfg.lds_scene) cfg.lds_bytes = 0;
     cfg.instanced = scene->dev.objs != nullptr;
+    cfg.textured = scene->dev.tex != nullptr;
     if (cfg.instanced) { cfg.lds_scene = false; cfg.lds_bytes = 0; }      // (the staged variants carry no instance code)
     cfg.own_test = cfg.lds_scene;
     cfg.ref_tree_bytes = cfg.lds_scene ? (((size_t)scene->dev.n_nodes * (sizeof(GpuNode) + sizeof(uint32_t)) + 15) & ~(size_t)15) : 0;
@@ -325,10 +326,11 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     WfLaunchCfg cfg;
     { int rc = make_launch_cfg(ctx, scene, cfg); if (rc != BDPT_OK) return rc; }
     const size_t kept_per_slot = cfg.own_test ? shadow_per_slot : 0;      // contributions kept by k_conn_gen<., true>
+    const size_t rec_doubles = cfg.textured ? 13 : 10;                     // words of a vertex record (device_core.h)
     if (!pipeline_can_walk(scene)) return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     if (n_owned >= ((int64_t)1 << 31)) return fail(BDPT_ERR_UNSUPPORTED, "more than 2^31 pixels in one call");
     // bytes of state per sample slot
-    const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 6 + vslots * 10 * sizeof(double) +
+    const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 6 + vslots * rec_doubles * sizeof(double) +
                             vis_words * sizeof(unsigned long long) + (shadow_per_slot * 8 + kept_per_slot * 3) * sizeof(double) +
                             (connections ? 8 : 0);        // (the slack of the shadow queue, see conn_blocks below)
     const size_t n_counters = 8 + 8 * (size_t)(depth > 0 ? depth : 1);      // (+ one k_redo list size per closest-hit traversal launch)
@@ -354,7 +356,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     int want_streams = kn.streams;
     // room for the 256-byte alignment of the 15 arrays of a workspace and for its counters
     const size_t per_stream_overhead = 17 * 256 + align256(n_counters * 4) + (size_t)kConnSlackPerBlock * 8 * sizeof(double) +
-                                       (size_t)kVtxGroup * (vslots * 10 + kept_per_slot * 3) * sizeof(double);     // (vertex arrays hold whole groups of slots)
+                                       (size_t)kVtxGroup * (vslots * rec_doubles + kept_per_slot * 3) * sizeof(double);     // (vertex arrays hold whole groups of slots)
     if (budget / want_streams <= per_stream_overhead + per_slot * (size_t)spp) want_streams = 1;
     if (budget <= per_stream_overhead + per_slot * (size_t)spp)
         return fail(BDPT_ERR_UNSUPPORTED, fixed_ws ? "the samples of one pixel exceed the static workspace (samples per pixel x depth too large for bdpt_render_device_static)"
@@ -390,7 +392,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const size_t o_tri = take(ns * 4), o_ctr = take(ns * 4), o_cnt = take(ns * 4);
     const size_t o_q0 = take(ns * 4), o_q1 = take(ns * 4), o_cq = take(ns * 4);
     const uint64_t ns_grouped = (ns + kVtxGroup - 1) / kVtxGroup * kVtxGroup;      // whole groups of slots
-    const size_t o_vtx = take(ns_grouped * vslots * 10 * 8), o_vis = take(ns * vis_words * 8), o_sh = take(shadow_cap * 8 * 8);
+    const size_t o_vtx = take(ns_grouped * vslots * rec_doubles * 8), o_vis = take(ns * vis_words * 8), o_sh = take(shadow_cap * 8 * 8);
     const size_t o_contrib = take(ns_grouped * kept_per_slot * 3 * 8);
     const size_t o_counters = take(n_counters * 4);
     // Measured: the batches in flight run 2.5 % faster when their workspaces lie at least ~30 GB apart in the
@@ -449,7 +451,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         wb.contrib = reinterpret_cast<double*>(base + o_contrib);
         wb.shadow = reinterpret_cast<double*>(base + o_sh); wb.counters = reinterpret_cast<uint32_t*>(base + o_counters);
         wb.ns = ns; wb.shadow_cap = shadow_cap; wb.vis_words = vis_words;
-        wb.vtx_words = (uint32_t)(vslots * 10); wb.contrib_words = (uint32_t)(kept_per_slot * 3);
+        wb.vtx_words = (uint32_t)(vslots * rec_doubles); wb.contrib_words = (uint32_t)(kept_per_slot * 3);
         wb.ray_len_ptr = nullptr;
         wb.ray_len = ray_len;
     }
@@ -770,12 +772,16 @@ int upload_pipeline_tables(bdpt_context* ctx, bdpt_scene* s) {
     d.n_mats = (uint32_t)h.mats.size();
     d.n_lights = s->composite ? h.n_lights : (uint32_t)h.light_tris.size();
     d.ref_nested = h.ref_nested ? 1u : 0u;
-    const bool inst = !h.objs.empty();
+    const bool inst = !h.objs.empty() || s->cx_host.textured;      // (textured scenes run the kernels of scenes with instances)
     d.objs = inst ? reinterpret_cast<const CxObject*>(base + off_objs) : nullptr;
     d.xobj = inst ? reinterpret_cast<const int32_t*>(base + off_xobj) : nullptr;
     d.pos_obj = inst ? reinterpret_cast<const int32_t*>(base + off_pobj) : nullptr;
     d.obj_leaf = inst ? reinterpret_cast<const uint32_t*>(base + off_oleaf) : nullptr;
     d.obj_pos0 = inst ? reinterpret_cast<const uint32_t*>(base + off_opos) : nullptr;
+    const bool tex = s->composite && s->cx_host.textured;
+    d.tex = tex ? s->cx_dev.tex : nullptr;
+    d.perlin = tex ? s->cx_dev.perlin : nullptr;
+    d.image_bytes = tex ? s->cx_dev.image_bytes : nullptr;
     return BDPT_OK;
 }
 
@@ -973,8 +979,8 @@ int bdpt_scene_create_composite(bdpt_context* ctx, const double* tri_vertices, c
     d.n_media = 0;
     for (const CxObject& ob : h.objs) d.n_media += (ob.flags & kCxMedium) ? 1u : 0u;
     d.pad = 0;
-    // Instances without media or textures also get the tables of the render pipeline; everything else is rendered by
-    // the single kernel alone.
+    // A scene without media also gets the tables of the render pipeline; media are rendered by the single kernel alone
+    // (their random draws are tied to the reference's visiting order).
     s->pipeline = false;
     if (h.pipeline_ok && !std::getenv("BDPT_COMPOSITE_SINGLE_KERNEL")) {
         try {

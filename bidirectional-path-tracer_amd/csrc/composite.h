@@ -15,21 +15,6 @@
 
 namespace bdpt {
 
-// src/materials/textures/texture.h
-struct CxTexture {
-    double rgb[3];
-    double scale;                  // noise: scale; checker: inv_scale = 1.0 / scale (texture.h:31)
-    int32_t type;                  // BDPT_TEX_*
-    int32_t a, b;                  // checker: even / odd texture; image: width / height
-    uint32_t data;                 // noise: index of its tables in `perlin`; image: first byte in `image_bytes`
-};
-
-// What a perlin object holds (perlin.h:53-57)
-struct CxPerlin {
-    double randvec[256][3];
-    int32_t perm_x[256], perm_y[256], perm_z[256];
-};
-
 // In the node table a leaf reference >= 0 is a triangle id and a reference <= -2 the object -(ref + 2);
 // -1 marks an interior record, as in GpuNode.  Record 0 is the root of the world's tree; every tree of the table is
 // threaded by itself and ends in kEndOfTree.
@@ -67,7 +52,8 @@ struct CxHostScene {
     uint32_t n_lights = 0;               // size of the light collection (the tables hold one dummy entry when it is empty)
     std::vector<uint32_t> node_parent;   // parent of every record of `nodes` inside its own tree (kEndOfTree for a root)
     std::vector<uint32_t> first_triangle, mesh_triangles;   // per object: its mesh
-    bool pipeline_ok = false;            // no medium and no texture: the scene can also run on the render pipeline
+    bool pipeline_ok = false;            // no medium: the scene can also run on the render pipeline
+    bool textured = false;               // some material carries a texture
     std::vector<int32_t> world_leaves;   // leaf references of the world's tree in the reference's visiting order
     uint32_t n_world_nodes = 0;          // records [0, n_world_nodes) are the world's tree
     uint32_t tree_depth = 0;

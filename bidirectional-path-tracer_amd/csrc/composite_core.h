@@ -5,6 +5,7 @@
 #ifndef BDPT_COMPOSITE_CORE_H
 #define BDPT_COMPOSITE_CORE_H
 
+#include "../../include/bdpt_amd.h"
 #include "bdpt_types.h"
 #include "device_core.h"
 
@@ -192,6 +193,80 @@ BDPT_DEV void cx_surface(const Sc& sc, V3 o, V3 d, const CxHit& h, CxSurf& s) {
     }
     s.p = p; s.n = n;
     s.mat = sc.tris[h.tri].material;
+}
+
+// ------------------------------------------------------------------ textures (src/materials/textures)
+// perlin::noise + perlin_interp, perlin.h:16-36,75-92
+BDPT_DEV double cx_perlin_noise(const CxPerlin& pn, V3 p) {
+    const double fx = __builtin_floor(p.x), fy = __builtin_floor(p.y), fz = __builtin_floor(p.z);
+    const double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    const double uu = u * u * (3 - 2 * u);
+    const double vv = v * v * (3 - 2 * v);
+    const double ww = w * w * (3 - 2 * w);
+    double accum = 0.0;
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++) {
+                const int idx = pn.perm_x[(i + di) & 255] ^ pn.perm_y[(j + dj) & 255] ^ pn.perm_z[(k + dk) & 255];
+                const V3 cv = mk(pn.randvec[idx][0], pn.randvec[idx][1], pn.randvec[idx][2]);
+                const V3 weight_v = mk(u - di, v - dj, w - dk);
+                accum += (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) * (dk * ww + (1 - dk) * (1 - ww)) *
+                         dot(cv, weight_v);
+            }
+    return accum;
+}
+// perlin::turb, perlin.h:38-50
+BDPT_DEV double cx_perlin_turb(const CxPerlin& pn, V3 p, int depth) {
+    double accum = 0.0;
+    V3 temp_p = p;
+    double weight = 1.0;
+    for (int i = 0; i < depth; i++) {
+        accum += weight * cx_perlin_noise(pn, temp_p);
+        weight *= 0.5;
+        temp_p = mk(temp_p.x * 2, temp_p.y * 2, temp_p.z * 2);
+    }
+    return __builtin_fabs(accum);
+}
+
+// texture::value(u, v, p), texture.h
+// `Sc`: any scene view with members tex, perlin, image_bytes
+template <class Sc>
+__device__ __noinline__ V3 cx_texture(const Sc& sc, int32_t id, double u, double v, V3 p) {
+    for (;;) {
+        const CxTexture t = sc.tex[id];
+        if (t.type == BDPT_TEX_CHECKER) {                                  // texture.h:36-44 (scale holds inv_scale)
+            const int xi = (int)__builtin_floor(t.scale * p.x);
+            const int yi = (int)__builtin_floor(t.scale * p.y);
+            const int zi = (int)__builtin_floor(t.scale * p.z);
+            id = ((xi + yi + zi) % 2 == 0) ? t.a : t.b;
+            continue;
+        }
+        if (t.type == BDPT_TEX_NOISE) {                                    // texture.h:80-82
+            const double arg = t.scale * p.z + 10 * cx_perlin_turb(sc.perlin[t.data], p, 7);
+            double s, c;
+            det_sincos(arg, s, c);
+            return scl(1 + s, mk(.5, .5, .5));
+        }
+        if (t.type == BDPT_TEX_IMAGE) {                                    // texture.h:56-70, rtw_stb_image.h:63-73
+            if (t.b <= 0) return mk(0, 1, 1);
+            u = (u < 0.0) ? 0.0 : ((u > 1.0) ? 1.0 : u);
+            const double vc = (v < 0.0) ? 0.0 : ((v > 1.0) ? 1.0 : v);
+            v = 1.0 - vc;
+            int i = (int)(u * t.a);
+            int j = (int)(v * t.b);
+            i = (i < 0) ? 0 : ((i < t.a) ? i : t.a - 1);
+            j = (j < 0) ? 0 : ((j < t.b) ? j : t.b - 1);
+            const uint8_t* px = sc.image_bytes + t.data + ((size_t)j * (size_t)t.a + (size_t)i) * 3;
+            const double color_scale = 1.0 / 255.0;
+            return mk(color_scale * px[0], color_scale * px[1], color_scale * px[2]);
+        }
+        return ld3(t.rgb);                                                 // solid_color
+    }
+}
+template <class Sc>
+BDPT_DEV V3 cx_colour(const Sc& sc, const GpuMaterial& m, double u, double v, V3 p) {
+    return (m.pad > 0) ? cx_texture(sc, m.pad - 1, u, v, p) : ld3(m.rgb);
 }
 
 }  // namespace bdpt

@@ -265,6 +265,9 @@ BDPT_DEV bool visible(const Mem& mem, V3 a, V3 b, Counters& c) {
 // normal, throughput, material and three flags.  Delta vertices are never stored: connect_vertices
 // returns zero for them before looking at anything else (camera.h:441).
 constexpr int kVtxDoubles = 10;   // p[3] n[3] T[3] + one slot holding (material | flags)
+// With textured materials the colour a vertex can contribute with is a function of its hit (texture::value(u, v, p)),
+// not of its material alone: the record then also holds `f`, three more slots.
+constexpr int kVtxDoublesTextured = 13;
 constexpr uint32_t kVtxIsLight = 1u << 30;
 constexpr uint32_t kVtxFrontFace = 1u << 29;
 constexpr uint32_t kVtxMatMask = (1u << 29) - 1;
@@ -273,6 +276,7 @@ struct Vertex {
     V3 p, n, T;
     uint32_t info;
     uint32_t tri;        // the triangle the vertex lies on (upper half of the record's last slot)
+    V3 f;                // textured scenes only: emission of a vertex on an emitter (zero from behind), else its BSDF value
 };
 
 // SoA in global memory: element (slot, field) of thread g lives at ws[(slot*10 + field)*stride + g],
@@ -281,15 +285,18 @@ struct VertexStore {
     double* ws;
     uint64_t stride;
     uint64_t g;
+    template <bool TEX = false>
     BDPT_DEV void put(int slot, const Vertex& v) const {
-        double* b = ws + (uint64_t)slot * kVtxDoubles * stride + g;
+        double* b = ws + (uint64_t)slot * (TEX ? kVtxDoublesTextured : kVtxDoubles) * stride + g;
         b[0] = v.p.x; b[stride] = v.p.y; b[2 * stride] = v.p.z;
         b[3 * stride] = v.n.x; b[4 * stride] = v.n.y; b[5 * stride] = v.n.z;
         b[6 * stride] = v.T.x; b[7 * stride] = v.T.y; b[8 * stride] = v.T.z;
         b[9 * stride] = __longlong_as_double((long long)(((unsigned long long)v.tri << 32) | v.info));
+        if (TEX) { b[10 * stride] = v.f.x; b[11 * stride] = v.f.y; b[12 * stride] = v.f.z; }
     }
+    template <bool TEX = false>
     BDPT_DEV Vertex get(int slot) const {
-        const double* b = ws + (uint64_t)slot * kVtxDoubles * stride + g;
+        const double* b = ws + (uint64_t)slot * (TEX ? kVtxDoublesTextured : kVtxDoubles) * stride + g;
         Vertex v;
         v.p = mk(b[0], b[stride], b[2 * stride]);
         v.n = mk(b[3 * stride], b[4 * stride], b[5 * stride]);
@@ -297,6 +304,7 @@ struct VertexStore {
         const unsigned long long w = (unsigned long long)__double_as_longlong(b[9 * stride]);
         v.info = (uint32_t)w;
         v.tri = (uint32_t)(w >> 32);
+        v.f = TEX ? mk(b[10 * stride], b[11 * stride], b[12 * stride]) : mk(0, 0, 0);
         return v;
     }
 };
@@ -550,7 +558,12 @@ struct Emitter {
     Vertex ev;
     V3 o, d, T;
 };
-BDPT_DEV void sample_emitter(const SceneDev& sc, int depth, Rng& rng, Emitter& e) {
+// the colour of an emitter's material at a point of it: its solid colour
+struct SolidEmitterColour {
+    BDPT_DEV V3 operator()(const GpuMaterial& m, V3) const { return ld3(m.rgb); }
+};
+template <class Colour = SolidEmitterColour>
+BDPT_DEV void sample_emitter(const SceneDev& sc, int depth, Rng& rng, Emitter& e, const Colour& colour = Colour()) {
     e.valid = false;
     e.has_ray = false;
     if (!(depth > 0 && sc.n_lights > 0 && sc.light_total_area > 0.0)) return;     // camera.h:378-379, triangle.h:200-208
@@ -565,7 +578,7 @@ BDPT_DEV void sample_emitter(const SceneDev& sc, int depth, Rng& rng, Emitter& e
     V3 position = add(add(ld3(tr.v0), scl(u, ld3(tr.e1))), scl(v, ld3(tr.e2)));
     V3 normal = ld3(ax.normal);
     const GpuMaterial m = sc.mats[tr.material];
-    V3 emission = (m.type == 3) ? ld3(m.rgb) : mk(0, 0, 0);                // front_face = true (camera.h:389)
+    V3 emission = (m.type == 3) ? colour(m, position) : mk(0, 0, 0);       // front_face = true, u = v = 0 (camera.h:385-391)
     if (!(len2(emission) > 0)) return;                                     // camera.h:395-396
     e.valid = true;
     double pdf = 1.0 / sc.light_total_area;
@@ -574,6 +587,7 @@ BDPT_DEV void sample_emitter(const SceneDev& sc, int depth, Rng& rng, Emitter& e
     e.ev.T = divs(mk(1.0, 1.0, 1.0), pm);
     e.ev.info = (uint32_t)tr.material | kVtxIsLight | kVtxFrontFace;
     e.ev.tri = (uint32_t)tri_id;
+    e.ev.f = emission;
     V3 w;
     V3 ldir = onb_transform(normal, random_cosine_direction(rng), w);      // camera.h:420-423
     V3 dir_unit = unit(ldir);

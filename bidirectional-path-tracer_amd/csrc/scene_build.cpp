@@ -853,13 +853,14 @@ std::string build_composite_scene(const double* tv, const int32_t* tri_material,
     out.first_triangle.resize(n_obj);
     out.mesh_triangles.resize(n_obj);
     for (uint32_t k = 0; k < n_obj; k++) { out.first_triangle[k] = objects[k].first_triangle; out.mesh_triangles[k] = objects[k].n_triangles; }
-    out.pipeline_ok = true;                                   // instances only, solid colours only: see composite.h
+    out.pipeline_ok = true;                                   // no medium: see composite.h
     for (const CxObject& ob : out.objs) if (ob.flags & kCxMedium) out.pipeline_ok = false;
-    for (const GpuMaterial& m : out.mats) if (m.pad > 0) out.pipeline_ok = false;
+    out.textured = false;
+    for (const GpuMaterial& m : out.mats) if (m.pad > 0) out.textured = true;
     return std::string();
 }
 
-// Tables of the render pipeline (SceneDev) for a composite scene that holds instances only.  The leaf order is the
+// Tables of the render pipeline (SceneDev) for a composite scene without media.  The leaf order is the
 // reference's visiting order over the two-level structure: the leaves of the world's tree left to right, an object
 // standing for the triangles of its mesh in the order of the mesh's own tree.
 std::string build_instanced_pipeline(const CxHostScene& cx, HostScene& out) {
@@ -870,8 +871,7 @@ std::string build_instanced_pipeline(const CxHostScene& cx, HostScene& out) {
     out.node_parent = cx.node_parent;
     out.tris = cx.tris;
     out.aux = cx.aux;
-    out.mats = cx.mats;
-    for (GpuMaterial& m : out.mats) m.pad = 0;
+    out.mats = cx.mats;                                       // (pad: texture index + 1)
     out.light_tris = cx.light_tris;
     out.light_accum = cx.light_accum;
     out.light_total_area = cx.light_total_area;

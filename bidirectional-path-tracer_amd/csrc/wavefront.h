@@ -34,7 +34,7 @@ struct WfBuffers {
     uint64_t ns;
     uint64_t shadow_cap;
     uint32_t vis_words;
-    uint32_t vtx_words;       // words of `vtx` per slot (records x 10)
+    uint32_t vtx_words;       // words of `vtx` per slot (records x 10, or x 13 in a scene with textures)
     uint32_t contrib_words;   // words of `contrib` per slot (depth x 3)
 };
 
@@ -69,6 +69,7 @@ struct WfLaunchCfg {
     int redo_blocks;          // grid of k_redo (the rays of a launch that met an exact tie: few)
     bool lds_scene;
     bool instanced;       // the scene holds instances: traversal and shading kernels with the ray transform in front of the triangle test
+    bool textured;        // some material carries a texture (implies `instanced`: those kernels, with vertex records of kVtxDoublesTextured words)
     uint32_t conn_blocks; // workgroups of k_conn_gen (each may leave up to kConnSlackPerBlock unused entries in the shadow queue)
     bool own_test;        // k_conn_gen tests the light vertex's own triangle (from tables in LDS) and keeps the pairs' contributions
     size_t lds_bytes;

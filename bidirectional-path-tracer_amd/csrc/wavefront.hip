@@ -99,9 +99,10 @@ BDPT_DEV VertexStore slot_store(const WfBuffers& wb, uint32_t slot) {
     return st;
 }
 // material and flags of record `rec` (Vertex::info)
+template <bool TEX = false>
 BDPT_DEV uint32_t slot_vertex_info(const WfBuffers& wb, uint32_t slot, int rec) {
     const VertexStore st = slot_store(wb, slot);
-    return (uint32_t)__double_as_longlong(st.ws[((uint64_t)rec * kVtxDoubles + 9) * st.stride + st.g]);
+    return (uint32_t)__double_as_longlong(st.ws[((uint64_t)rec * (TEX ? kVtxDoublesTextured : kVtxDoubles) + 9) * st.stride + st.g]);
 }
 // kept contribution of the pair with light vertex `bi` (three words kVtxGroup apart), same grouping
 BDPT_DEV double* slot_contrib(const WfBuffers& wb, uint32_t slot, uint32_t bi) {
@@ -838,7 +839,11 @@ __global__ __launch_bounds__(kBlock) void k_redo(SceneDev sc, WfBuffers wb, cons
 }
 
 // ------------------------------------------------------------------ shading of one bounce
-template <bool EYE, bool STATS, bool LAMBERT, bool INSTANCED = false>
+// TEX (with INSTANCED): materials may carry a texture.  Its value at the hit (texture::value(u, v, p), material.h:45,135)
+// takes the place of the material's solid colour, and the vertex record keeps the colour the vertex can contribute
+// with; u and v are formed again from the ray and the hit triangle, by the operations that formed them in the
+// triangle test (the traversal kernels keep no u, v).
+template <bool EYE, bool STATS, bool LAMBERT, bool INSTANCED = false, bool TEX = false>
 __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
                                                   const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
                                                   uint32_t* count_out, int last_bounce, int store_vertices, unsigned long long* stats) {
@@ -893,7 +898,18 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
                     front_face = dot(d, m.normal) < 0;
                     normal = front_face ? m.normal : neg(m.normal);
                 }
+                if (TEX) {
+                    const int32_t tex1 = sc.mats[m.id].pad;
+                    if (tex1 > 0) {
+                        V3 to = o, td = d;
+                        if (ob >= 0) cx_to_object(sc.objs[ob], to, td);
+                        double t, u, v, det;
+                        (void)tri_candidate(sc.tris[r.tri], to, td, 0.001, t, u, v, det);
+                        m.rgb = cx_texture(sc, tex1 - 1, u, v, p);
+                    }
+                }
                 shade_surface<EYE, LAMBERT>(m, (int32_t)r.tri, p, normal, front_face, d, T, rng, bo);
+                if (TEX) bo.vx.f = (m.type == 3) ? (front_face ? m.rgb : mk(0, 0, 0)) : ((m.type == 0) ? divs(m.rgb, kPi) : mk(0, 0, 0));
             } else {
                 shade_bounce_at<EYE, LAMBERT>(sc, (uint32_t)pos, o, d, t_hit, T, rng, bo);
             }
@@ -902,7 +918,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             if (bo.keep && store_vertices) {       // (no vertex store in a scene that cannot form a connection)
                 uint32_t cnt = wb.counts[slot];
                 const uint32_t ne = cnt & 0xFFFu, nl = (cnt >> 12) & 0xFFFu;
-                slot_store(wb, slot).put(EYE ? (int)ne : depth + (int)nl, bo.vx);
+                slot_store(wb, slot).put<TEX>(EYE ? (int)ne : depth + (int)nl, bo.vx);
                 cnt += EYE ? 1u : (1u << 12);
                 if (EYE && !(bo.vx.info & kVtxIsLight)) cnt |= kCntEyeConnectable;
                 if (STATS) n_stored++;
@@ -999,7 +1015,12 @@ __global__ __launch_bounds__(kStageBlock) void k_shade_unidirectional(SceneDev s
 }
 
 // ------------------------------------------------------------------ light subpath start
-template <bool STATS>
+// the colour of an emitter's material at a point of it, textures included (u = v = 0 there, camera.h:385-391)
+struct TexturedEmitterColour {
+    const SceneDev& sc;
+    BDPT_DEV V3 operator()(const GpuMaterial& m, V3 position) const { return cx_colour(sc, m, 0.0, 0.0, position); }
+};
+template <bool STATS, bool TEX = false>
 __global__ __launch_bounds__(kStageBlock) void k_gen_light(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, uint32_t* queue_out,
                                                       uint32_t* count_out, unsigned long long* stats) {
     const uint32_t spp = (uint32_t)(cam.sqrt_spp * cam.sqrt_spp);
@@ -1029,10 +1050,11 @@ __global__ __launch_bounds__(kStageBlock) void k_gen_light(SceneDev sc, GpuCamer
             if (!(cnt & kCntEyeConnectable)) continue;
             Rng rng = slot_rng(cam, b, slot, wb.ctr[slot]);
             Emitter em;
-            sample_emitter(sc, depth, rng, em);
+            if (TEX) sample_emitter(sc, depth, rng, em, TexturedEmitterColour{sc});
+            else sample_emitter(sc, depth, rng, em);
             wb.ctr[slot] = rng.counter;
             if (!em.valid) continue;
-            slot_store(wb, slot).put(depth, em.ev);
+            slot_store(wb, slot).put<TEX>(depth, em.ev);
             if (STATS) n_stored++;
             wb.counts[slot] = cnt | (1u << 12);
             if (em.has_ray && depth - 1 > 0) {
@@ -1123,7 +1145,8 @@ BDPT_DEV PairMats stage_pair_mats(const SceneDev& sc, double* lds) {
 // the traversal finds sooner (measured on a 0.96 M-triangle lattice: 2 361 -> 1 446 Msamples/s with the test, on 10.2 M
 // triangles 1 826 -> 944, on the 51 k-triangle coffee machine 2 859 -> 2 791), so those scenes run the instantiation
 // without it (OWN_TEST = false).
-template <bool STATS, bool OWN_TEST>
+// TEX: the factors of a pair come from its vertices (Vertex::f), not from the material table.
+template <bool STATS, bool OWN_TEST, bool TEX = false>
 __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera cam, WfBuffers wb, int a,
                                                           const uint32_t* conn_count, uint32_t* shadow_count,
                                                           unsigned long long* stats) {
@@ -1176,7 +1199,7 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
                     if (STATS) n_pairs += n_light;
                     // an eye vertex on an emitter has a zero BSDF (material.h:35-37): every pair it forms
                     // contributes zero whatever the visibility, so no ray is spent on it
-                    const uint32_t info = slot_vertex_info(wb, slot, a);
+                    const uint32_t info = slot_vertex_info<TEX>(wb, slot, a);
                     if (!(info & kVtxIsLight)) mine[j] = n_light;
                 }
             }
@@ -1217,12 +1240,12 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
                 for (uint32_t step = kStageTile / 2; step; step >>= 1) el += (s_prefix[el + step] <= p) ? step : 0u;
                 slot = s_slot[el];
                 bi = p - s_prefix[el];
-                const Vertex cv = slot_store(wb, slot).get(a);
-                const Vertex lv = slot_store(wb, slot).get(depth + (int)bi);
-                const V3 f_cam = pmats.bsdf(sc, cv.info & kVtxMatMask);
+                const Vertex cv = slot_store(wb, slot).get<TEX>(a);
+                const Vertex lv = slot_store(wb, slot).get<TEX>(depth + (int)bi);
+                const V3 f_cam = TEX ? cv.f : pmats.bsdf(sc, cv.info & kVtxMatMask);   // (an eye vertex on an emitter never gets here)
                 V3 f_light = mk(0, 0, 0);
                 emit = !(len2(f_cam) <= 0) && pair_geometry(cv, lv, g);                                // camera.h:458-460
-                if (emit) { f_light = pmats.light_factor(sc, lv.info); emit = len2(f_light) > 0; }      // camera.h:462-469
+                if (emit) { f_light = TEX ? lv.f : pmats.light_factor(sc, lv.info); emit = len2(f_light) > 0; }      // camera.h:462-469
                 if (OWN_TEST && emit) {
                     GpuTri own = own_tris[lv.tri];
                     own.material = own_graze[lv.tri];
@@ -1274,7 +1297,7 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
 
 // adds the contributions of eye vertex `a` in light-vertex order (camera.h:316-320, 471-474).  KEPT: k_conn_gen left
 // the contribution of every pair it made a ray for in wb.contrib; otherwise the clear pairs are evaluated again here.
-template <bool KEPT>
+template <bool KEPT, bool TEX = false>
 __global__ __launch_bounds__(kBlock) void k_conn_accum(SceneDev sc, GpuCamera cam, WfBuffers wb, int a, const uint32_t* conn_count) {
     const uint32_t count = *conn_count;
     const int depth = cam.max_depth;
@@ -1285,7 +1308,7 @@ __global__ __launch_bounds__(kBlock) void k_conn_accum(SceneDev sc, GpuCamera ca
         if ((uint32_t)a >= (cnt & 0xFFFu)) continue;
         const int n_light = (int)((cnt >> 12) & 0xFFFu);
         Vertex cv;
-        if (!KEPT) cv = slot_store(wb, slot).get(a);
+        if (!KEPT) cv = slot_store(wb, slot).get<TEX>(a);
         V3 result = mk(wb.result[slot], wb.result[ns + slot], wb.result[2 * ns + slot]);
         bool changed = false;
         for (int bi = 0; bi < n_light; bi++) {
@@ -1295,10 +1318,15 @@ __global__ __launch_bounds__(kBlock) void k_conn_accum(SceneDev sc, GpuCamera ca
                 const double* cb = slot_contrib(wb, slot, (uint32_t)bi);
                 result = add(result, mk(cb[0], cb[kVtxGroup], cb[2 * kVtxGroup]));
             } else {
-                const Vertex lv = slot_store(wb, slot).get(depth + bi);
+                const Vertex lv = slot_store(wb, slot).get<TEX>(depth + bi);
                 PairGeom g;
                 V3 f_cam, f_light;
-                if (!pair_geometry(cv, lv, g) || !pair_factors(sc, cv, lv, f_cam, f_light)) continue;
+                if (!pair_geometry(cv, lv, g)) continue;
+                if (TEX) {
+                    f_cam = (cv.info & kVtxIsLight) ? mk(0, 0, 0) : cv.f;
+                    f_light = lv.f;
+                    if (len2(f_cam) <= 0 || !(len2(f_light) > 0)) continue;
+                } else if (!pair_factors(sc, cv, lv, f_cam, f_light)) continue;
                 result = add(result, pair_contribution(cv, lv, g, f_cam, f_light));
             }
             changed = true;
@@ -1594,6 +1622,16 @@ hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& w
                     hipStream_t st) {
     dim3 grid(cfg.stream_blocks), block(kStageBlock);
     const int last = last_bounce ? 1 : 0, keep = store_vertices ? 1 : 0;
+    if (cfg.textured) {
+        if (eye) {
+            if (stats) hipLaunchKernelGGL((k_shade<true, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+            else hipLaunchKernelGGL((k_shade<true, false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        } else {
+            if (stats) hipLaunchKernelGGL((k_shade<false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+            else hipLaunchKernelGGL((k_shade<false, false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        }
+        return hipGetLastError();
+    }
     if (cfg.instanced) {
         if (eye) {
             if (stats) hipLaunchKernelGGL((k_shade<true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
@@ -1628,7 +1666,10 @@ hipError_t wf_shade_unidirectional(const SceneDev& sc, const GpuCamera& cam, con
 hipError_t wf_gen_light(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* queue_out,
                         uint32_t* count_out, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
     dim3 grid(cfg.stream_blocks), block(kStageBlock);
-    if (stats) hipLaunchKernelGGL((k_gen_light<true>), grid, block, 0, st, sc, cam, wb, b, queue_out, count_out, stats);
+    if (cfg.textured) {
+        if (stats) hipLaunchKernelGGL((k_gen_light<true, true>), grid, block, 0, st, sc, cam, wb, b, queue_out, count_out, stats);
+        else hipLaunchKernelGGL((k_gen_light<false, true>), grid, block, 0, st, sc, cam, wb, b, queue_out, count_out, stats);
+    } else if (stats) hipLaunchKernelGGL((k_gen_light<true>), grid, block, 0, st, sc, cam, wb, b, queue_out, count_out, stats);
     else hipLaunchKernelGGL((k_gen_light<false>), grid, block, 0, st, sc, cam, wb, b, queue_out, count_out, stats);
     return hipGetLastError();
 }
@@ -1649,6 +1690,9 @@ hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers
         const size_t shm = cfg.ref_tree_bytes + (size_t)sc.n_tris * (sizeof(GpuTri) + 8);
         if (stats) hipLaunchKernelGGL((k_conn_gen<true, true>), grid, block, shm, st, sc, cam, wb, a, conn_count, shadow_count, stats);
         else hipLaunchKernelGGL((k_conn_gen<false, true>), grid, block, shm, st, sc, cam, wb, a, conn_count, shadow_count, stats);
+    } else if (cfg.textured) {
+        if (stats) hipLaunchKernelGGL((k_conn_gen<true, false, true>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
+        else hipLaunchKernelGGL((k_conn_gen<false, false, true>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
     } else {
         if (stats) hipLaunchKernelGGL((k_conn_gen<true, false>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
         else hipLaunchKernelGGL((k_conn_gen<false, false>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
@@ -1659,6 +1703,7 @@ hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers
 hipError_t wf_conn_accum(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
                          const WfLaunchCfg& cfg, hipStream_t st) {
     if (cfg.own_test) hipLaunchKernelGGL((k_conn_accum<true>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
+    else if (cfg.textured) hipLaunchKernelGGL((k_conn_accum<false, true>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
     else hipLaunchKernelGGL((k_conn_accum<false>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
     return hipGetLastError();
 }

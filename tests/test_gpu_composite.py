@@ -85,7 +85,7 @@ def test_hits_match_reference(case):
     assert_bit_equal(hits2, hits, name + ": counting and plain query kernels")
 
 
-PIPELINE_CASES = ("cx_instances", "cx_lattice")      # instances only: these also run on the render pipeline
+PIPELINE_CASES = ("cx_instances", "cx_lattice", "cx_textures")      # no medium: these also run on the render pipeline
 
 
 def test_adversarial_queries_match_reference_on_both_walkers(case, ctx):
@@ -112,8 +112,9 @@ def test_adversarial_queries_match_reference_on_both_walkers(case, ctx):
 
 
 def test_instances_render_on_the_pipeline(case):
-    """Scenes with instances only take the wavefront pipeline by default (its traversal launches can be timed, which
-    the single kernel has none of) and the single kernel on request; both give the reference's framebuffer."""
+    """Scenes without a medium (instances, textures) take the wavefront pipeline by default (its traversal launches can
+    be timed, which the single kernel has none of) and the single kernel on request; both give the reference's
+    framebuffer."""
     import torch
     name, flat, sc, g = case
     cam = capi.camera_initialize(flat.camera)

@@ -1,0 +1,33 @@
+"""Speed of the composite scenes that stay on the single kernel (textures, media) beside the plain Cornell box on the pipeline.
+    python tools/cx_speed.py [image_width] [spp]"""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import oracle_lib
+capi = importlib.import_module("bidirectional-path-tracer_amd.capi")
+scenes = importlib.import_module("bidirectional-path-tracer_amd.scenes")
+width = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+ctx = capi.Context(0)
+o = oracle_lib.Oracle()
+for name, builder in (("cornell (plain)", lambda: scenes.cornell_box(width, spp, 10)), ("cornell_instances", lambda: scenes.cornell_instances(width, spp, 10)),
+                      ("cornell_textures", lambda: scenes.cornell_textures(width, spp, 10)), ("cornell_smoke", lambda: scenes.cornell_smoke(width, spp, 10))):
+    flat = builder()
+    if hasattr(flat, "objects"):
+        flat.image_bytes = [np.ascontiguousarray(t.image) for t in flat.textures if t.type == scenes.TEX_IMAGE]
+        flat.perlin_tables = [t for t in o.scene(flat).perlin_tables()]
+    sc = ctx.scene(flat)
+    cam = capi.camera_initialize(flat.camera)
+    fb = torch.zeros((cam.image_height, cam.image_width, 3), dtype=torch.float64, device="cuda")
+    sc.render_device(cam, fb.data_ptr(), seed=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sc.render_device(cam, fb.data_ptr(), seed=1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("%-18s %4d px %3d spp: frame %8.1f ms, %7.0f Msamples/s" % (name, width, cam.sqrt_spp ** 2, dt * 1e3,
+          cam.image_width * cam.image_height * cam.sqrt_spp ** 2 * cam.max_depth / dt / 1e6), flush=True)
+    sc.close()
