@@ -131,7 +131,8 @@ struct bdpt_scene {
     CxSceneDev cx_dev{};
     void* d_cx_blob = nullptr;
     size_t cx_blob_bytes = 0;
-    bool pipeline = true;          // false: a composite scene that only the single-kernel path can render (media, textures)
+    bool pipeline = true;          // false: a composite scene with media (the four-wide hierarchy cannot answer for it)
+    bool ordered = false;          // such a scene: the pipeline's stages around walks in the reference's own order
     void* d_blob = nullptr;
     size_t blob_bytes = 0;
     uint32_t n_materials = 0;
@@ -275,6 +276,7 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     if (!cfg.lds_scene) cfg.lds_bytes = 0;
     cfg.instanced = scene->dev.objs != nullptr;
     cfg.textured = scene->dev.tex != nullptr;
+    cfg.ordered = scene->ordered;
     if (cfg.instanced) { cfg.lds_scene = false; cfg.lds_bytes = 0; }      // (the staged variants carry no instance code)
     cfg.own_test = cfg.lds_scene;
     cfg.ref_tree_bytes = cfg.lds_scene ? (((size_t)scene->dev.n_nodes * (sizeof(GpuNode) + sizeof(uint32_t)) + 15) & ~(size_t)15) : 0;
@@ -321,13 +323,14 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     // (the unidirectional estimator forms no connections; it keeps one record per level of its recursion instead)
     const bool connections = !unidirectional && (scene->host.has_lambertian || stats_mode != 0);
     const size_t vslots = unidirectional ? (size_t)(depth > 0 ? depth : 1) : (connections ? 2 * (size_t)(depth > 0 ? depth : 1) : 0);
-    const uint32_t vis_words = connections ? (uint32_t)((depth > 0 ? depth : 1) + 63) / 64 : 0;
-    const size_t shadow_per_slot = connections ? (size_t)(depth > 0 ? depth : 1) : 0;
+    // (a scene with media keeps no shadow queue: its pairs are traced one after the other, k_conn_ordered)
+    const uint32_t vis_words = (connections && !scene->ordered) ? (uint32_t)((depth > 0 ? depth : 1) + 63) / 64 : 0;
+    const size_t shadow_per_slot = (connections && !scene->ordered) ? (size_t)(depth > 0 ? depth : 1) : 0;
     WfLaunchCfg cfg;
     { int rc = make_launch_cfg(ctx, scene, cfg); if (rc != BDPT_OK) return rc; }
     const size_t kept_per_slot = cfg.own_test ? shadow_per_slot : 0;      // contributions kept by k_conn_gen<., true>
     const size_t rec_doubles = cfg.textured ? 13 : 10;                     // words of a vertex record (device_core.h)
-    if (!pipeline_can_walk(scene)) return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+    if (!scene->ordered && !pipeline_can_walk(scene)) return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     if (n_owned >= ((int64_t)1 << 31)) return fail(BDPT_ERR_UNSUPPORTED, "more than 2^31 pixels in one call");
     // bytes of state per sample slot
     const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 6 + vslots * rec_doubles * sizeof(double) +
@@ -526,7 +529,8 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
             const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
             const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
             const int nxt = (k == 0) ? 0 : (cur ^ 1);
-            { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st, wb.queue[nxt], eye_redo(k)); }); if (rc != BDPT_OK) return rc; }
+            { int rc = timed(0, st, [&] { return cfg.ordered ? wf_walk_ordered(scene->dev, gcam, wb, b, q_in, c_in, n_slots, cfg, st)
+                                                             : wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st, wb.queue[nxt], eye_redo(k)); }); if (rc != BDPT_OK) return rc; }
             HIP_TRY(wf_shade(scene->dev, gcam, wb, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, connections, cfg,
                              stats, st));
             cur = nxt;
@@ -536,7 +540,8 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
             HIP_TRY(wf_gen_light(scene->dev, gcam, wb, b, wb.queue[0], light_count(0), cfg, stats, st));
             cur = 0;
             for (int k = 0; k < depth - 1; k++) {
-                { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st, wb.queue[cur ^ 1], light_redo(k)); }); if (rc != BDPT_OK) return rc; }
+                { int rc = timed(0, st, [&] { return cfg.ordered ? wf_walk_ordered(scene->dev, gcam, wb, b, wb.queue[cur], light_count(k), 0, cfg, st)
+                                                                 : wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st, wb.queue[cur ^ 1], light_redo(k)); }); if (rc != BDPT_OK) return rc; }
                 HIP_TRY(wf_shade(scene->dev, gcam, wb, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
                                  light_count(k + 1), k == depth - 2, true, cfg, stats, st));
                 cur ^= 1;
@@ -544,7 +549,8 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         }
         // connections: camera.h:316-320
         if (connections) HIP_TRY(wf_conn_prepare(gcam, wb, b, conn_count, cfg, stats, st));
-        for (int a = 0; a < depth && connections; a++) {
+        if (connections && cfg.ordered) HIP_TRY(wf_conn_ordered(scene->dev, gcam, wb, b, conn_count, cfg, st));
+        for (int a = 0; a < depth && connections && !cfg.ordered; a++) {
             HIP_TRY(wf_conn_gen(scene->dev, gcam, wb, a, conn_count, shadow_count(a), cfg, stats, st));
             { int rc = timed(1, st, [&] { return wf_occlude(scene->dev, wb, shadow_count(a), 0, shadow_cursor(a), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
             HIP_TRY(wf_conn_accum(scene->dev, gcam, wb, a, conn_count, cfg, st));
@@ -584,8 +590,9 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     // Reference-equivalent counters need the reference's traversal of every shadow ray: that is the single-kernel
     // path, which also takes over when the four-wide hierarchy is deeper than the pipeline's traversal stack.
     // Everything else runs the wavefront pipeline unless the caller asks otherwise.
-    const bool cx_single = scene->composite && (!scene->pipeline || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || unidirectional || !pipeline_can_walk(scene));
-    const bool single_kernel = cx_single || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || !pipeline_can_walk(scene);
+    const bool cx_single = scene->composite && (scene->ordered ? (stats_mode != 0 || (p->flags & BDPT_RENDER_MEGAKERNEL) || unidirectional)
+                                                               : (!scene->pipeline || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || unidirectional || !pipeline_can_walk(scene)));
+    const bool single_kernel = cx_single || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || (!scene->ordered && !pipeline_can_walk(scene));
     if (cx_single && fixed_ws) return fail(BDPT_ERR_UNSUPPORTED, "this composite scene renders on the single-kernel path, which allocates");
     if (fixed_ws && (single_kernel || time_stages))
         return fail(BDPT_ERR_UNSUPPORTED, pipeline_can_walk(scene)
@@ -772,13 +779,13 @@ int upload_pipeline_tables(bdpt_context* ctx, bdpt_scene* s) {
     d.n_mats = (uint32_t)h.mats.size();
     d.n_lights = s->composite ? h.n_lights : (uint32_t)h.light_tris.size();
     d.ref_nested = h.ref_nested ? 1u : 0u;
-    const bool inst = !h.objs.empty() || s->cx_host.textured;      // (textured scenes run the kernels of scenes with instances)
+    const bool inst = !h.objs.empty() || (s->composite && s->cx_host.textured);      // (textured scenes run the kernels of scenes with instances)
     d.objs = inst ? reinterpret_cast<const CxObject*>(base + off_objs) : nullptr;
     d.xobj = inst ? reinterpret_cast<const int32_t*>(base + off_xobj) : nullptr;
     d.pos_obj = inst ? reinterpret_cast<const int32_t*>(base + off_pobj) : nullptr;
     d.obj_leaf = inst ? reinterpret_cast<const uint32_t*>(base + off_oleaf) : nullptr;
     d.obj_pos0 = inst ? reinterpret_cast<const uint32_t*>(base + off_opos) : nullptr;
-    const bool tex = s->composite && s->cx_host.textured;
+    const bool tex = s->composite && (s->cx_host.textured || !s->cx_host.pipeline_ok);    // (media: the kernels with 13-word vertex records)
     d.tex = tex ? s->cx_dev.tex : nullptr;
     d.perlin = tex ? s->cx_dev.perlin : nullptr;
     d.image_bytes = tex ? s->cx_dev.image_bytes : nullptr;
@@ -982,7 +989,7 @@ int bdpt_scene_create_composite(bdpt_context* ctx, const double* tri_vertices, c
     // A scene without media also gets the tables of the render pipeline; media are rendered by the single kernel alone
     // (their random draws are tied to the reference's visiting order).
     s->pipeline = false;
-    if (h.pipeline_ok && !std::getenv("BDPT_COMPOSITE_SINGLE_KERNEL")) {
+    if (!std::getenv("BDPT_COMPOSITE_SINGLE_KERNEL")) {
         try {
             err = build_instanced_pipeline(s->cx_host, s->host);
         } catch (const std::bad_alloc&) {
@@ -991,7 +998,8 @@ int bdpt_scene_create_composite(bdpt_context* ctx, const double* tri_vertices, c
         if (!err.empty()) { (void)hipFree(s->d_cx_blob); delete s; return fail(BDPT_ERR_INVALID_ARGUMENT, err); }
         int rc = upload_pipeline_tables(ctx, s);
         if (rc != BDPT_OK) { (void)hipFree(s->d_cx_blob); delete s; return rc; }
-        s->pipeline = true;
+        s->pipeline = h.pipeline_ok;
+        s->ordered = !h.pipeline_ok;
     }
     *out = s;
     return BDPT_OK;

@@ -363,7 +363,8 @@ BDPT_DEV void shade_bounce_at(const SceneDev& sc, uint32_t pos, V3 o, V3 d, doub
 }
 
 // (p, normal, front_face: the hit_record as the world's hit() returned it; d: the ray's direction)
-template <bool EYE, bool LAMBERT>
+// MEDIA: the material may also be the isotropic phase function of a constant_medium (material.h:149-172)
+template <bool EYE, bool LAMBERT, bool MEDIA = false>
 BDPT_DEV void shade_surface(const ShadeMat& m, int32_t tri, V3 p, V3 normal, bool front_face, V3 d, V3 throughput, Rng& rng, Bounce& out);
 
 template <bool EYE, bool LAMBERT>
@@ -375,11 +376,11 @@ BDPT_DEV void shade_bounce(const ShadeMat& m, int32_t tri, V3 o, V3 d, double t_
     shade_surface<EYE, LAMBERT>(m, tri, p, normal, front_face, d, throughput, rng, out);
 }
 
-template <bool EYE, bool LAMBERT>
+template <bool EYE, bool LAMBERT, bool MEDIA>
 BDPT_DEV void shade_surface(const ShadeMat& m, int32_t tri, V3 p, V3 normal, bool front_face, V3 d, V3 throughput, Rng& rng, Bounce& out) {
     const int32_t mat_id = m.id;
 
-    out.keep = (m.type == 0 || m.type == 3);
+    out.keep = (m.type == 0 || m.type == 3 || (MEDIA && m.type == 4));
     out.vx.p = p; out.vx.n = normal; out.vx.T = throughput;
     out.vx.info = (uint32_t)mat_id | (m.type == 3 ? kVtxIsLight : 0u) | (front_face ? kVtxFrontFace : 0u);
     out.vx.tri = (uint32_t)tri;
@@ -416,6 +417,15 @@ BDPT_DEV void shade_surface(const ShadeMat& m, int32_t tri, V3 p, V3 normal, boo
             direction = refract(unit_direction, normal, ri);
         out.T = mulv(throughput, mk(1.0, 1.0, 1.0));
         out.d = direction;
+        out.cont = true;
+        return;
+    }
+    if (MEDIA && m.type == 4) {                                           // isotropic, material.h:154-168 + pdf.h:17-28 + camera.h:361-368
+        V3 scattered = random_unit_vector(rng);
+        double pdf_value = 1 / (4 * kPi);
+        double scattering_pdf = 1 / (4 * kPi);
+        out.T = divs(scl(scattering_pdf, mulv(throughput, m.rgb)), pdf_value);
+        out.d = scattered;
         out.cont = true;
         return;
     }

@@ -879,6 +879,7 @@ std::string build_instanced_pipeline(const CxHostScene& cx, HostScene& out) {
     out.tree_depth = cx.tree_depth;
     out.objs = cx.objs;
     for (uint32_t i = 0; i < n_tri; i++) if (out.mats[out.tris[i].material].type == BDPT_LAMBERTIAN) out.has_lambertian = true;
+    for (const CxObject& ob : cx.objs) if (ob.flags & kCxMedium) out.has_lambertian = true;      // (its phase function forms connections like a lambertian surface)
 
     // every box of a tree contains the boxes below it (what reference_reaches relies on), checked tree by tree
     out.ref_nested = true;

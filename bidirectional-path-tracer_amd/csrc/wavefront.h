@@ -43,6 +43,8 @@ constexpr uint32_t kVtxGroup = 64;
 
 // wb.hit_tri value of a ray whose closest hit the traversal kernel leaves to the walk over the reference's own tree
 constexpr int32_t kHitRedo = -2;
+// scenes with media (k_walk_ordered): wb.hit_tri value kHitMedium0 - k of a ray that ends inside the medium of object k
+constexpr int32_t kHitMedium0 = -3;
 
 // entries of the closest-hit walk's stack (up to three pushes per level of the four-wide tree)
 constexpr int kQuadStackEntries = 64;
@@ -69,6 +71,8 @@ struct WfLaunchCfg {
     int redo_blocks;          // grid of k_redo (the rays of a launch that met an exact tie: few)
     bool lds_scene;
     bool instanced;       // the scene holds instances: traversal and shading kernels with the ray transform in front of the triangle test
+    bool ordered;         // the scene holds a constant_medium: rays are traced in the reference's own order (k_walk_ordered,
+                          // k_conn_ordered) and the shading kernels know the isotropic phase function (implies `textured`)
     bool textured;        // some material carries a texture (implies `instanced`: those kernels, with vertex records of kVtxDoublesTextured words)
     uint32_t conn_blocks; // workgroups of k_conn_gen (each may leave up to kConnSlackPerBlock unused entries in the shadow queue)
     bool own_test;        // k_conn_gen tests the light vertex's own triangle (from tables in LDS) and keeps the pairs' contributions
@@ -104,6 +108,11 @@ hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBa
                            const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
 hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
                        uint32_t* shadow_count, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
+// scenes with media: closest-hit walk in the reference's order for the rays of a queue, and the whole connection stage
+hipError_t wf_walk_ordered(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const uint32_t* queue,
+                           const uint32_t* count_ptr, uint32_t count_imm, const WfLaunchCfg& cfg, hipStream_t st);
+hipError_t wf_conn_ordered(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const uint32_t* conn_count,
+                           const WfLaunchCfg& cfg, hipStream_t st);
 // number of queue entries: *shadow_count, or count_imm when shadow_count is null
 hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t count_imm, uint32_t* cursor,
                       const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);

@@ -838,12 +838,142 @@ __global__ __launch_bounds__(kBlock) void k_redo(SceneDev sc, WfBuffers wb, cons
     }
 }
 
+// ------------------------------------------------------------------ scenes with media: the walk in the reference's order
+// constant_medium::hit draws a random number inside bvh_node::hit (constant_medium.h:40), from the sample's stream, so
+// the rays of such a scene are traced over the reference's own two-level tree in the reference's order, one ray per
+// lane, the sample's stream position read and written back.  Result codes as k_traverse writes them, plus the codes
+// <= kHitMedium0 of a hit inside a medium.
+__global__ __launch_bounds__(kBlock) void k_walk_ordered(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue,
+                                                         const uint32_t* count_ptr, uint32_t count_imm) {
+    const uint32_t count = count_ptr ? *count_ptr : count_imm;
+    const uint64_t ns = wb.ns;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
+        const uint32_t slot = queue ? queue[k] : k;
+        int pi, pj, ps;
+        if (!slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
+        const V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
+        const V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
+        const uint32_t ctr0 = wb.ctr[slot];
+        Rng rng = slot_rng(cam, b, slot, ctr0);
+        Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        CxHit h;
+        int32_t code = -1;
+        if (cx_walk<kStatsOff>(sc, o, d, 0.001, kInf, h, c, rng)) {
+            code = (h.tri < 0) ? kHitMedium0 - h.obj : (int32_t)((h.obj >= 0 ? sc.obj_pos0[h.obj] : 0u) + sc.tri_pos[h.tri]);
+            wb.hit[slot] = h.t;
+        }
+        wb.hit_tri[slot] = code;
+        if (rng.counter != ctr0) wb.ctr[slot] = rng.counter;
+    }
+}
+
+// camera::bidirectional_color's connection loop (camera.h:316-320) for such a scene: the pairs of a sample one after
+// the other, each with the reference's full closest-hit query behind camera::visible (camera.h:437) - a medium on the
+// way draws from the sample's stream, so neither the order of a sample's pairs nor a pair that will contribute nothing
+// can be left out.  Samples have between 1 and depth^2 pairs: a workgroup takes a tile of samples, orders them by their
+// number of pairs (counting sort in LDS) and works in rounds - round r is pair r of every sample that has one, which
+// is a prefix of the ordered tile, one sample per thread - with stream position and radiance of the samples in LDS
+// between the rounds.  (One sample per lane with a loop over its pairs: a wave then takes as long as its longest
+// sample, 3.7 x as long in a Cornell box with smoke.)
+constexpr uint32_t kOrderedMaxPairs = 1024;       // histogram size: samples with more pairs share the last bin
+__global__ __launch_bounds__(kStageBlock) void k_conn_ordered(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* conn_count) {
+    __shared__ uint32_t s_slot[kStageTile], s_cnt[kStageTile], s_ctr[kStageTile];
+    __shared__ unsigned long long s_key[kStageTile];
+    __shared__ double s_res[3][kStageTile];
+    __shared__ uint16_t s_order[kStageTile];
+    __shared__ uint32_t s_hist[kOrderedMaxPairs + 1];
+    __shared__ uint32_t s_max;
+    const uint32_t count = *conn_count;
+    const int depth = cam.max_depth;
+    const uint64_t ns = wb.ns;
+    // bins in use: a sample has at most depth x depth pairs
+    const uint32_t nb = ((uint64_t)depth * (uint64_t)depth < kOrderedMaxPairs) ? (uint32_t)(depth * depth) : kOrderedMaxPairs;
+    for (uint32_t tile = blockIdx.x * kStageTile; tile < count; tile += gridDim.x * kStageTile) {
+        const uint32_t n_el = (count - tile < kStageTile) ? count - tile : kStageTile;
+        for (uint32_t i = threadIdx.x; i <= nb; i += kStageBlock) s_hist[i] = 0u;
+        if (threadIdx.x == 0) s_max = 0u;
+        __syncthreads();
+        // state of the tile's samples; histogram of their pair counts
+        for (uint32_t el = threadIdx.x; el < n_el; el += kStageBlock) {
+            const uint32_t slot = wb.conn_queue[tile + el];
+            const uint32_t cnt = wb.counts[slot];
+            s_slot[el] = slot;
+            s_cnt[el] = cnt;
+            s_ctr[el] = wb.ctr[slot];
+            int pi, pj, ps;
+            slot_to_sample(cam, b, slot, pi, pj, ps);
+            s_key[el] = stream_key(b.seed, (uint64_t)pj * (uint64_t)cam.width + (uint64_t)pi, (uint64_t)ps);
+            s_res[0][el] = wb.result[slot]; s_res[1][el] = wb.result[ns + slot]; s_res[2][el] = wb.result[2 * ns + slot];
+            const uint32_t pairs = (cnt & 0xFFFu) * ((cnt >> 12) & 0xFFFu);
+            atomicAdd(&s_hist[pairs < nb ? pairs : nb], 1u);
+            atomicMax(&s_max, pairs);
+        }
+        __syncthreads();
+        // s_hist[p] := number of samples with MORE than p pairs (= the samples of round p); the ordered tile
+        if (threadIdx.x == 0) {
+            uint32_t above = 0;
+            for (int p = (int)nb; p >= 0; p--) { const uint32_t here = s_hist[p]; s_hist[p] = above; above += here; }
+        }
+        __syncthreads();
+        for (uint32_t el = threadIdx.x; el < n_el; el += kStageBlock) {
+            const uint32_t cnt = s_cnt[el];
+            const uint32_t pairs = (cnt & 0xFFFu) * ((cnt >> 12) & 0xFFFu);
+            // samples with more pairs first: those with exactly `pairs` stand behind the s_hist[pairs] that have more
+            const uint32_t at = atomicAdd(&s_hist[pairs < nb ? pairs : nb], 1u);
+            s_order[at] = (uint16_t)el;
+        }
+        __syncthreads();
+        // (s_hist[p] now counts the samples with p pairs or more; round r takes the first s_hist[r + 1] of the order)
+        const uint32_t rounds = s_max;
+        for (uint32_t r = 0; r < rounds; r++) {
+            uint32_t n_r;
+            if (r + 1 <= nb) n_r = s_hist[r + 1];
+            else n_r = s_hist[nb];                            // (beyond the histogram: checked per sample below)
+            for (uint32_t i = threadIdx.x; i < n_r; i += kStageBlock) {
+                const uint32_t el = s_order[i];
+                const uint32_t cnt = s_cnt[el];
+                const uint32_t n_light = (cnt >> 12) & 0xFFFu;
+                if (r >= (cnt & 0xFFFu) * n_light) continue;
+                const uint32_t a = r / n_light, bi = r - a * n_light;
+                const uint32_t slot = s_slot[el];
+                const VertexStore store = slot_store(wb, slot);
+                const Vertex cv = store.get<true>((int)a);
+                const Vertex lv = store.get<true>(depth + (int)bi);
+                V3 term = mk(0, 0, 0);
+                PairGeom g;
+                if (pair_geometry(cv, lv, g)) {                                       // camera.h:444-453, 426-436
+                    Rng rng;
+                    rng.key = s_key[el];
+                    rng.counter = s_ctr[el];
+                    Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    CxHit tmp;
+                    const bool blocked = cx_walk<kStatsOff>(sc, g.origin, g.dir_unit, 0.001, g.max_t, tmp, c, rng);
+                    s_ctr[el] = rng.counter;
+                    if (!blocked) {
+                        const V3 f_cam = (cv.info & kVtxIsLight) ? mk(0, 0, 0) : cv.f;     // material.h:35-37
+                        if (!(len2(f_cam) <= 0) && len2(lv.f) > 0) term = pair_contribution(cv, lv, g, f_cam, lv.f);
+                    }
+                }
+                s_res[0][el] = s_res[0][el] + term.x; s_res[1][el] = s_res[1][el] + term.y; s_res[2][el] = s_res[2][el] + term.z;
+            }
+            __syncthreads();
+        }
+        for (uint32_t el = threadIdx.x; el < n_el; el += kStageBlock) {
+            const uint32_t slot = s_slot[el];
+            wb.result[slot] = s_res[0][el]; wb.result[ns + slot] = s_res[1][el]; wb.result[2 * ns + slot] = s_res[2][el];
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ shading of one bounce
 // TEX (with INSTANCED): materials may carry a texture.  Its value at the hit (texture::value(u, v, p), material.h:45,135)
 // takes the place of the material's solid colour, and the vertex record keeps the colour the vertex can contribute
 // with; u and v are formed again from the ray and the hit triangle, by the operations that formed them in the
 // triangle test (the traversal kernels keep no u, v).
-template <bool EYE, bool STATS, bool LAMBERT, bool INSTANCED = false, bool TEX = false>
+// MEDIA (with TEX): the hits come from k_walk_ordered; a negative code <= kHitMedium0 stands for a point inside the
+// medium -(code - kHitMedium0) (constant_medium.h:45-50: normal (1, 0, 0), front face, the medium's phase function).
+template <bool EYE, bool STATS, bool LAMBERT, bool INSTANCED = false, bool TEX = false, bool MEDIA = false>
 __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
                                                   const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
                                                   uint32_t* count_out, int last_bounce, int store_vertices, unsigned long long* stats) {
@@ -867,10 +997,11 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             int pi, pj, ps;
             if (!slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
             int32_t pos = wb.hit_tri[slot];           // position of the hit triangle in the reference's leaf order
+            const bool medium = MEDIA && pos <= kHitMedium0;
             double t_hit = 0.0;
-            if (pos >= 0) t_hit = wb.hit[slot];        // (k_redo has resolved the rays the traversal kernel left open)
+            if (pos >= 0 || medium) t_hit = wb.hit[slot];        // (k_redo has resolved the rays the traversal kernel left open)
             V3 T = mk(wb.thr[slot], wb.thr[ns + slot], wb.thr[2 * ns + slot]);
-            if (pos < 0) {
+            if (pos < 0 && !medium) {
                 if (EYE) {   // camera.h:337-338: background_contrib (0) += throughput * background
                     V3 bg = add(mk(0, 0, 0), mulv(T, ld3(cam.background)));
                     wb.result[slot] = bg.x; wb.result[ns + slot] = bg.y; wb.result[2 * ns + slot] = bg.z;
@@ -882,7 +1013,16 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             const uint32_t ctr0 = wb.ctr[slot];
             Rng rng = slot_rng(cam, b, slot, ctr0);
             Bounce bo;
-            if (INSTANCED) {
+            if (MEDIA && medium) {
+                const int32_t mat_id = sc.objs[kHitMedium0 - pos].phase_material;
+                const GpuMaterial gm = sc.mats[mat_id];
+                ShadeMat m;
+                m.normal = mk(1, 0, 0); m.rgb = ld3(gm.rgb); m.fuzz = gm.fuzz; m.ior = gm.ior; m.type = gm.type; m.id = mat_id;
+                const V3 p = add(o, scl(t_hit, d));
+                if (gm.pad > 0) m.rgb = cx_texture(sc, gm.pad - 1, 0.0, 0.0, p);
+                shade_surface<EYE, LAMBERT, MEDIA>(m, 0, p, mk(1, 0, 0), true, d, T, rng, bo);
+                bo.vx.f = (m.type == 4) ? divs(m.rgb, 4 * kPi) : mk(0, 0, 0);
+            } else if (INSTANCED) {
                 // one copy of the material code: the hit_record first (through the object's wrappers or not), then shading
                 const GpuShadeRec r = sc.shade[pos];
                 ShadeMat m;
@@ -908,7 +1048,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
                         m.rgb = cx_texture(sc, tex1 - 1, u, v, p);
                     }
                 }
-                shade_surface<EYE, LAMBERT>(m, (int32_t)r.tri, p, normal, front_face, d, T, rng, bo);
+                shade_surface<EYE, LAMBERT, MEDIA>(m, (int32_t)r.tri, p, normal, front_face, d, T, rng, bo);
                 if (TEX) bo.vx.f = (m.type == 3) ? (front_face ? m.rgb : mk(0, 0, 0)) : ((m.type == 0) ? divs(m.rgb, kPi) : mk(0, 0, 0));
             } else {
                 shade_bounce_at<EYE, LAMBERT>(sc, (uint32_t)pos, o, d, t_hit, T, rng, bo);
@@ -1611,6 +1751,18 @@ hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* qu
     return hipGetLastError();
 }
 
+hipError_t wf_walk_ordered(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const uint32_t* queue,
+                           const uint32_t* count_ptr, uint32_t count_imm, const WfLaunchCfg& cfg, hipStream_t st) {
+    hipLaunchKernelGGL(k_walk_ordered, dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, b, queue, count_ptr, count_imm);
+    return hipGetLastError();
+}
+
+hipError_t wf_conn_ordered(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const uint32_t* conn_count,
+                           const WfLaunchCfg& cfg, hipStream_t st) {
+    hipLaunchKernelGGL(k_conn_ordered, dim3(cfg.stream_blocks), dim3(kStageBlock), 0, st, sc, cam, wb, b, conn_count);
+    return hipGetLastError();
+}
+
 hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t count_imm, uint32_t* cursor,
                       const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
     return launch_traverse<true>(sc, wb, nullptr, shadow_count, count_imm, cursor, cfg, stats, st);
@@ -1622,6 +1774,11 @@ hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& w
                     hipStream_t st) {
     dim3 grid(cfg.stream_blocks), block(kStageBlock);
     const int last = last_bounce ? 1 : 0, keep = store_vertices ? 1 : 0;
+    if (cfg.ordered) {
+        if (eye) hipLaunchKernelGGL((k_shade<true, false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        else hipLaunchKernelGGL((k_shade<false, false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        return hipGetLastError();
+    }
     if (cfg.textured) {
         if (eye) {
             if (stats) hipLaunchKernelGGL((k_shade<true, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);

@@ -241,15 +241,15 @@ typedef struct bdpt_object {
  * the SAME range: they share one mesh (one bvh_node behind several wrappers, as shared_ptr allows in the reference)
  * and stand in the list in the order of their indices; different ranges must not overlap.  Light triangles (the `lights` collection) must be triangles that
  * belong to no object; n_lights == 0 selects all of those.
- * How the resulting scene is rendered depends on what it holds.  No medium: the wavefront pipeline, like any other
- * scene - its traversal kernels transform the ray in front of an instanced triangle's test, its shading kernels
- * evaluate texture::value(u, v, p) at the hit (u, v formed again from ray and triangle by the triangle test's own
- * operations) and keep the resulting colour in the vertex record - and every bdpt_render* entry point and flag
- * applies.  A medium: the single-kernel path (one thread per sample, the reference's own traversal order -
- * constant_medium::hit draws its random number INSIDE the BVH walk, constant_medium.h:40, so the visiting order is
- * part of the result); bdpt_render_device_static, BDPT_RENDER_TIME_STAGES and BDPT_RENDER_COUNT_WORK's meaning do
- * not apply there.  For a composite scene BDPT_RENDER_MEGAKERNEL, BDPT_RENDER_COUNT_STATS and
- * BDPT_RENDER_UNIDIRECTIONAL always take the single kernel.  bdpt_trace_closest* / bdpt_visible answer for every composite scene; query i draws from stream
+ * Every composite scene renders on the wavefront pipeline, like any other scene.  Without a medium its traversal
+ * kernels transform the ray in front of an instanced triangle's test, its shading kernels evaluate
+ * texture::value(u, v, p) at the hit (u, v formed again from ray and triangle by the triangle test's own operations)
+ * and keep the resulting colour in the vertex record.  With a medium the rays are traced over the reference's own
+ * trees in the reference's order instead, the pairs of a sample one after the other - constant_medium::hit draws its
+ * random number INSIDE the BVH walk (constant_medium.h:40), so visiting order, running upper bound and the order of a
+ * sample's shadow rays are part of the result.  For a composite scene BDPT_RENDER_MEGAKERNEL, BDPT_RENDER_COUNT_STATS and
+ * BDPT_RENDER_UNIDIRECTIONAL take the single-kernel path (one thread per sample over the same trees), and so does
+ * BDPT_RENDER_COUNT_WORK for a scene with a medium; bdpt_render_device_static and BDPT_RENDER_TIME_STAGES do not apply there.  bdpt_trace_closest* / bdpt_visible answer for every composite scene; query i draws from stream
  * (seed 0, pixel i, sample 0).  A hit inside a medium reports -(2 + object index) as its triangle id and u = v = 0 (the
  * reference leaves them unset); a hit on a shared mesh reports the triangle of the mesh.
  * An isotropic material with an image texture is refused: the reference reads unset u, v there (constant_medium.h:45-50, material.h:155). */

@@ -1,5 +1,5 @@
 """Speed of the composite scenes that stay on the single kernel (textures, media) beside the plain Cornell box on the pipeline.
-    python tools/cx_speed.py [image_width] [spp]"""
+    python tools/cx_speed.py [image_width] [spp] [only: part of a scene's name]"""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,10 +11,13 @@ capi = importlib.import_module("bidirectional-path-tracer_amd.capi")
 scenes = importlib.import_module("bidirectional-path-tracer_amd.scenes")
 width = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+only = sys.argv[3] if len(sys.argv) > 3 else ""
 ctx = capi.Context(0)
 o = oracle_lib.Oracle()
 for name, builder in (("cornell (plain)", lambda: scenes.cornell_box(width, spp, 10)), ("cornell_instances", lambda: scenes.cornell_instances(width, spp, 10)),
                       ("cornell_textures", lambda: scenes.cornell_textures(width, spp, 10)), ("cornell_smoke", lambda: scenes.cornell_smoke(width, spp, 10))):
+    if only not in name:
+        continue
     flat = builder()
     if hasattr(flat, "objects"):
         flat.image_bytes = [np.ascontiguousarray(t.image) for t in flat.textures if t.type == scenes.TEX_IMAGE]
