@@ -521,6 +521,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
             const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
             const int nxt = (k == 0) ? 0 : (cur ^ 1);
             { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st, wb.queue[nxt], eye_redo(k)); }); if (rc != BDPT_OK) return rc; }
+            HIP_TRY(wf_redo(scene->dev, wb, cfg, st, wb.queue[nxt], eye_redo(k)));
             HIP_TRY(wf_shade_unidirectional(scene->dev, gcam, wb, b, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k, k == depth - 1, cfg, stats, st));
             cur = nxt;
         }
@@ -531,6 +532,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
             const int nxt = (k == 0) ? 0 : (cur ^ 1);
             { int rc = timed(0, st, [&] { return cfg.ordered ? wf_walk_ordered(scene->dev, gcam, wb, b, q_in, c_in, n_slots, cfg, st)
                                                              : wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st, wb.queue[nxt], eye_redo(k)); }); if (rc != BDPT_OK) return rc; }
+            if (!cfg.ordered) HIP_TRY(wf_redo(scene->dev, wb, cfg, st, wb.queue[nxt], eye_redo(k)));
             HIP_TRY(wf_shade(scene->dev, gcam, wb, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, connections, cfg,
                              stats, st));
             cur = nxt;
@@ -542,6 +544,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
             for (int k = 0; k < depth - 1; k++) {
                 { int rc = timed(0, st, [&] { return cfg.ordered ? wf_walk_ordered(scene->dev, gcam, wb, b, wb.queue[cur], light_count(k), 0, cfg, st)
                                                                  : wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st, wb.queue[cur ^ 1], light_redo(k)); }); if (rc != BDPT_OK) return rc; }
+                if (!cfg.ordered) HIP_TRY(wf_redo(scene->dev, wb, cfg, st, wb.queue[cur ^ 1], light_redo(k)));
                 HIP_TRY(wf_shade(scene->dev, gcam, wb, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
                                  light_count(k + 1), k == depth - 2, true, cfg, stats, st));
                 cur ^= 1;
@@ -668,6 +671,7 @@ int trace_closest_pipeline(bdpt_context* ctx, const bdpt_scene* scene, const dou
         HIP_TRY(hipMemsetAsync(cursor, 0, 3 * sizeof(uint32_t), stream));
         HIP_TRY(wf_rays_in(rays, m, wb, tmax, ray_len, stream));
         HIP_TRY(wf_extend(scene->dev, wb, nullptr, nullptr, m, cursor, cfg, nullptr, stream, reinterpret_cast<uint32_t*>(base + o_redo), cursor + 2));
+        HIP_TRY(wf_redo(scene->dev, wb, cfg, stream, reinterpret_cast<uint32_t*>(base + o_redo), cursor + 2));
         HIP_TRY(wf_hits_out(scene->dev, rays, m, wb, d_hits + 11 * first, stream));
     }
     return BDPT_OK;

@@ -89,11 +89,13 @@ struct WfLaunchCfg {
 // counts of the work done, accumulated by the kernels when `stats` is non-null (bdpt_stats order)
 hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const WfLaunchCfg& cfg,
                       hipStream_t st);
-// closest-hit traversal of a queue, then k_redo over the rays it left open.  redo_list: room for one entry per ray of
+// closest-hit traversal of a queue; wf_redo, called next on the same stream, launches k_redo over the rays it left
+// open (two calls so that a caller can time the traversal launch by itself).  redo_list: room for one entry per ray of
 // the launch (the queue the following shading launch will fill is free until then); redo_count: zero when called
 hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                      uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st,
                      uint32_t* redo_list, uint32_t* redo_count);
+hipError_t wf_redo(const SceneDev& sc, const WfBuffers& wb, const WfLaunchCfg& cfg, hipStream_t st, uint32_t* redo_list, uint32_t* redo_count);
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
                     const uint32_t* queue_in, const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
                     uint32_t* count_out, bool last_bounce, bool store_vertices, const WfLaunchCfg& cfg, unsigned long long* stats,

@@ -874,7 +874,7 @@ __global__ __launch_bounds__(kBlock) void k_walk_ordered(SceneDev sc, GpuCamera 
 // number of pairs (counting sort in LDS) and works in rounds - round r is pair r of every sample that has one, which
 // is a prefix of the ordered tile, one sample per thread - with stream position and radiance of the samples in LDS
 // between the rounds.  (One sample per lane with a loop over its pairs: a wave then takes as long as its longest
-// sample, 3.7 x as long in a Cornell box with smoke.)
+// sample, twice as long in a Cornell box with smoke.)
 constexpr uint32_t kOrderedMaxPairs = 1024;       // histogram size: samples with more pairs share the last bin
 __global__ __launch_bounds__(kStageBlock) void k_conn_ordered(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* conn_count) {
     __shared__ uint32_t s_slot[kStageTile], s_cnt[kStageTile], s_ctr[kStageTile];
@@ -1743,8 +1743,10 @@ static hipError_t launch_traverse(const SceneDev& sc, const WfBuffers& wb, const
 hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
                      uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st,
                      uint32_t* redo_list, uint32_t* redo_count) {
-    hipError_t e = launch_traverse<false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
-    if (e != hipSuccess) return e;
+    return launch_traverse<false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+}
+
+hipError_t wf_redo(const SceneDev& sc, const WfBuffers& wb, const WfLaunchCfg& cfg, hipStream_t st, uint32_t* redo_list, uint32_t* redo_count) {
     // few rays, if any: a small grid that returns at once when the list is empty
     if (cfg.instanced) hipLaunchKernelGGL(k_redo<true>, dim3(cfg.redo_blocks), dim3(kBlock), 0, st, sc, wb, redo_list, redo_count);
     else hipLaunchKernelGGL(k_redo<false>, dim3(cfg.redo_blocks), dim3(kBlock), 0, st, sc, wb, redo_list, redo_count);
