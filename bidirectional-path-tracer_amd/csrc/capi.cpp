@@ -596,7 +596,7 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     const bool cx_single = scene->composite && (scene->ordered ? (stats_mode != 0 || (p->flags & BDPT_RENDER_MEGAKERNEL) || unidirectional)
                                                                : (!scene->pipeline || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || unidirectional || !pipeline_can_walk(scene)));
     const bool single_kernel = cx_single || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || (!scene->ordered && !pipeline_can_walk(scene));
-    if (cx_single && fixed_ws) return fail(BDPT_ERR_UNSUPPORTED, "this composite scene renders on the single-kernel path, which allocates");
+    if (cx_single && fixed_ws) return fail(BDPT_ERR_UNSUPPORTED, "these flags put a composite scene on the single-kernel path, which allocates");
     if (fixed_ws && (single_kernel || time_stages))
         return fail(BDPT_ERR_UNSUPPORTED, pipeline_can_walk(scene)
                         ? "bdpt_render_device_static supports the flags BDPT_RENDER_COUNT_WORK, BDPT_RENDER_TIME_KERNEL and BDPT_RENDER_UNIDIRECTIONAL only"
@@ -990,8 +990,9 @@ int bdpt_scene_create_composite(bdpt_context* ctx, const double* tri_vertices, c
     d.n_media = 0;
     for (const CxObject& ob : h.objs) d.n_media += (ob.flags & kCxMedium) ? 1u : 0u;
     d.pad = 0;
-    // A scene without media also gets the tables of the render pipeline; media are rendered by the single kernel alone
-    // (their random draws are tied to the reference's visiting order).
+    // Every composite scene also gets the tables of the render pipeline.  A scene with media uses only part of them: its
+    // rays are walked over the two-level table in the reference's own order (its random draws are tied to that order),
+    // so the four-wide hierarchy stays unused and ray / visibility queries go to the kernels of composite.hip.
     s->pipeline = false;
     if (!std::getenv("BDPT_COMPOSITE_SINGLE_KERNEL")) {
         try {

@@ -52,7 +52,7 @@ struct CxHostScene {
     uint32_t n_lights = 0;               // size of the light collection (the tables hold one dummy entry when it is empty)
     std::vector<uint32_t> node_parent;   // parent of every record of `nodes` inside its own tree (kEndOfTree for a root)
     std::vector<uint32_t> first_triangle, mesh_triangles;   // per object: its mesh
-    bool pipeline_ok = false;            // no medium: the scene can also run on the render pipeline
+    bool pipeline_ok = false;            // no medium: the pipeline's four-wide hierarchy can answer for the scene
     bool textured = false;               // some material carries a texture
     std::vector<int32_t> world_leaves;   // leaf references of the world's tree in the reference's visiting order
     uint32_t n_world_nodes = 0;          // records [0, n_world_nodes) are the world's tree

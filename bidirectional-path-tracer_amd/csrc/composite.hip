@@ -1,4 +1,6 @@
-// Kernels for composite scenes (composite.h): instances (translate / rotate_y), textures and constant-density media.
+// Single-kernel renderer and query kernels for composite scenes (composite.h): instances (translate / rotate_y),
+// textures and constant-density media.  (The render pipeline of wavefront.hip renders them too; this path serves the
+// counting mode, the unidirectional estimator and the queries of scenes with media.)
 // One thread renders one sample from start to end and walks the reference's own trees in the reference's order:
 // constant_medium::hit draws a random number every time the walk reaches a medium whose boundary the ray crosses
 // (src/materials/volumes/constant_medium.h:40), so the visiting order, the running upper bound of the interval and

@@ -1,7 +1,8 @@
 // Device-side walk over a composite scene's trees in the reference's own visiting order (composite.h): the world's
 // bvh_node tree whose leaves are triangles or objects, and one tree per mesh.  Shared by the single-kernel renderer of
-// composite scenes (composite.hip) and by the pipeline's kernels, which fall back to it for exact ties (wavefront.hip).
-// `Sc` is any scene view with members nodes, tris, aux, objs.  Citations are to the reference renderer's source tree.
+// composite scenes (composite.hip) and by the pipeline's kernels (wavefront.hip), which use it for exact ties and, in a
+// scene with media, for every ray; the texture routines (src/materials/textures) are shared the same way.
+// `Sc` is any scene view with members nodes, tris, aux, objs (and tex, perlin, image_bytes for the textures).  Citations are to the reference renderer's source tree.
 #ifndef BDPT_COMPOSITE_CORE_H
 #define BDPT_COMPOSITE_CORE_H
 
