@@ -50,6 +50,22 @@ def test_static_workspace_render_matches_render_device(scenes):
     sc.close(); sc2.close(); ctx.close()
 
 
+def test_static_workspace_renders_composite_scenes(scenes):
+    """Scenes with instances, textures (13-word vertex records) and media (rays walked in the reference's order, no
+    shadow queue) lay their state out differently in the same static array."""
+    from conftest import composite_scene
+    ctx = capi.Context(0)
+    for name in ("cx_textures", "cx_smoke", "cx_instances"):
+        flat, g = composite_scene(scenes, name)
+        sc = ctx.scene(flat)
+        cam = capi.camera_initialize(flat.camera)
+        got, want = render_both(sc, cam, seed=int(g["render_seed"][0]))
+        assert (want.view(np.uint64) == np.ascontiguousarray(g["framebuffer"]).view(np.uint64)).all(), name
+        assert (got.view(np.uint64) == want.view(np.uint64)).all(), name
+        sc.close()
+    ctx.close()
+
+
 def test_static_workspace_limits_are_reported(scenes):
     import torch
     ctx = capi.Context(0)
