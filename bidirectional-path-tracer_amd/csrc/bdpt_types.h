@@ -136,6 +136,8 @@ struct SceneDev {
     const GpuMaterial* mats;
     const GpuShadeRec* shade;       // per entry of `stris`
     const uint32_t* tri_pos;        // per triangle of `tris`: its position in `stris`
+    const uint32_t* tri_xpos;       // position in `xtris` of what Vertex::tri names: a triangle of `tris`, or - in a scene with
+                                    // instances - an entry of `stris`
     const uint32_t* light_tris;     // the light collection (triangle ids, insertion order)
     const double* light_accum;      // running sums of the areas exactly as triangle.h:212-219 accumulates them
     double light_total_area;

@@ -64,6 +64,7 @@ struct Knobs {
     int leaf;
     int leaf_inner;       // 0: half the leaf threshold
     int chunk;
+    int no_first_leaf;    // 1: shadow rays start at the root like all others
 };
 
 Knobs read_knobs() {
@@ -78,6 +79,7 @@ Knobs read_knobs() {
     k.leaf = env_int("BDPT_WF_LEAF", 32, 1, 64);
     k.leaf_inner = env_int("BDPT_WF_LEAF_INNER", 0, 0, 64);
     k.chunk = env_int("BDPT_WF_CHUNK", 512, 1, 1 << 20);
+    k.no_first_leaf = env_int("BDPT_WF_NO_FIRST_LEAF", 0, 0, 1);
     return k;
 }
 
@@ -333,9 +335,16 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     if (!scene->ordered && !pipeline_can_walk(scene)) return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     if (n_owned >= ((int64_t)1 << 31)) return fail(BDPT_ERR_UNSUPPORTED, "more than 2^31 pixels in one call");
     // bytes of state per sample slot
+    // A shadow ray of a scene too large for LDS first tests the triangle its far end lies on (WfBuffers::shadow_first, a
+    // ninth, 32-bit word per ray): +17 % on the 51 k-triangle coffee machine, +9 % on a 0.96 M-triangle lattice.  That
+    // test is one access to a random place of the triangle table, so it pays while the table stays in the 256 MB
+    // last-level cache: on 10.2 M triangles (0.8 GB) it is an HBM round trip per ray and costs 8 %.
+    const bool first_leaf = !cfg.lds_scene && !cfg.ordered && scene->dev.tri_xpos != nullptr &&
+                            scene->host.xtris.size() * sizeof(GpuTri) <= ((size_t)256 << 20) && !ctx->knobs.no_first_leaf;
     const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 6 + vslots * rec_doubles * sizeof(double) +
                             vis_words * sizeof(unsigned long long) + (shadow_per_slot * 8 + kept_per_slot * 3) * sizeof(double) +
-                            (connections ? 8 : 0);        // (the slack of the shadow queue, see conn_blocks below)
+                            (first_leaf ? shadow_per_slot * 4 : 0) +
+                            (connections ? 9 : 0);        // (the slack of the shadow queue, see conn_blocks below)
     const size_t n_counters = 8 + 8 * (size_t)(depth > 0 ? depth : 1);      // (+ one k_redo list size per closest-hit traversal launch)
     // Wavefront state of all batches in flight.  Large batches mean few, long launches (a frame is tens of thousands
     // of them), so a host that wants the last tenth of throughput raises the limit (bdpt_context_set_workspace_limit).
@@ -358,7 +367,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     }
     int want_streams = kn.streams;
     // room for the 256-byte alignment of the 15 arrays of a workspace and for its counters
-    const size_t per_stream_overhead = 17 * 256 + align256(n_counters * 4) + (size_t)kConnSlackPerBlock * 8 * sizeof(double) +
+    const size_t per_stream_overhead = 18 * 256 + align256(n_counters * 4) + (size_t)kConnSlackPerBlock * 9 * sizeof(double) +
                                        (size_t)kVtxGroup * (vslots * rec_doubles + kept_per_slot * 3) * sizeof(double);     // (vertex arrays hold whole groups of slots)
     if (budget / want_streams <= per_stream_overhead + per_slot * (size_t)spp) want_streams = 1;
     if (budget <= per_stream_overhead + per_slot * (size_t)spp)
@@ -397,6 +406,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const uint64_t ns_grouped = (ns + kVtxGroup - 1) / kVtxGroup * kVtxGroup;      // whole groups of slots
     const size_t o_vtx = take(ns_grouped * vslots * rec_doubles * 8), o_vis = take(ns * vis_words * 8), o_sh = take(shadow_cap * 8 * 8);
     const size_t o_contrib = take(ns_grouped * kept_per_slot * 3 * 8);
+    const size_t o_first = take(first_leaf ? shadow_cap * 4 : 0);
     const size_t o_counters = take(n_counters * 4);
     // Measured: the batches in flight run 2.5 % faster when their workspaces lie at least ~30 GB apart in the
     // allocation than when they are neighbours (a total that large without the spacing does not help).  A frame big
@@ -453,6 +463,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         wb.vtx = reinterpret_cast<double*>(base + o_vtx); wb.vis = reinterpret_cast<unsigned long long*>(base + o_vis);
         wb.contrib = reinterpret_cast<double*>(base + o_contrib);
         wb.shadow = reinterpret_cast<double*>(base + o_sh); wb.counters = reinterpret_cast<uint32_t*>(base + o_counters);
+        wb.shadow_first = first_leaf ? reinterpret_cast<uint32_t*>(base + o_first) : nullptr;
         wb.ns = ns; wb.shadow_cap = shadow_cap; wb.vis_words = vis_words;
         wb.vtx_words = (uint32_t)(vslots * rec_doubles); wb.contrib_words = (uint32_t)(kept_per_slot * 3);
         wb.ray_len_ptr = nullptr;
@@ -726,7 +737,8 @@ int upload_pipeline_tables(bdpt_context* ctx, bdpt_scene* s) {
     size_t off_pobj = off_xobj + align256(h.xobj.size() * sizeof(int32_t));
     size_t off_oleaf = off_pobj + align256(h.pos_obj.size() * sizeof(int32_t));
     size_t off_opos = off_oleaf + align256(h.obj_leaf.size() * sizeof(uint32_t));
-    size_t total = off_opos + align256(h.obj_pos0.size() * sizeof(uint32_t));
+    size_t off_xpos = off_opos + align256(h.obj_pos0.size() * sizeof(uint32_t));
+    size_t total = off_xpos + align256(h.tri_xpos.size() * sizeof(uint32_t));
     hipError_t e = hipMalloc(&s->d_blob, total);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(scene)");
     s->blob_bytes = total;
@@ -752,6 +764,7 @@ int upload_pipeline_tables(bdpt_context* ctx, bdpt_scene* s) {
         {off_pobj, h.pos_obj.data(), h.pos_obj.size() * sizeof(int32_t)},
         {off_oleaf, h.obj_leaf.data(), h.obj_leaf.size() * sizeof(uint32_t)},
         {off_opos, h.obj_pos0.data(), h.obj_pos0.size() * sizeof(uint32_t)},
+        {off_xpos, h.tri_xpos.data(), h.tri_xpos.size() * sizeof(uint32_t)},
     };
     for (auto& p : parts) {
         if (p.bytes == 0) continue;
@@ -773,6 +786,7 @@ int upload_pipeline_tables(bdpt_context* ctx, bdpt_scene* s) {
     d.mats = reinterpret_cast<const GpuMaterial*>(base + off_mats);
     d.shade = reinterpret_cast<const GpuShadeRec*>(base + off_shade);
     d.tri_pos = reinterpret_cast<const uint32_t*>(base + off_tpos);
+    d.tri_xpos = h.tri_xpos.empty() ? nullptr : reinterpret_cast<const uint32_t*>(base + off_xpos);
     d.light_tris = reinterpret_cast<const uint32_t*>(base + off_ltri);
     d.light_accum = reinterpret_cast<const double*>(base + off_lacc);
     d.light_total_area = h.light_total_area;
@@ -783,7 +797,7 @@ int upload_pipeline_tables(bdpt_context* ctx, bdpt_scene* s) {
     d.n_mats = (uint32_t)h.mats.size();
     d.n_lights = s->composite ? h.n_lights : (uint32_t)h.light_tris.size();
     d.ref_nested = h.ref_nested ? 1u : 0u;
-    const bool inst = !h.objs.empty() || (s->composite && s->cx_host.textured);      // (textured scenes run the kernels of scenes with instances)
+    const bool inst = h.vertex_names_entry;      // (instances, textures, media: the kernels of scenes with instances)
     d.objs = inst ? reinterpret_cast<const CxObject*>(base + off_objs) : nullptr;
     d.xobj = inst ? reinterpret_cast<const int32_t*>(base + off_xobj) : nullptr;
     d.pos_obj = inst ? reinterpret_cast<const int32_t*>(base + off_pobj) : nullptr;

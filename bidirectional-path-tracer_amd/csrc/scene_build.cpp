@@ -369,6 +369,9 @@ static void build_traversal_hierarchy(HostScene& out, const std::vector<Box3>& w
         out.bary_margin = std::fmax(1e-6, 64.0 * 0x1p-52 * 4.0 * out.coord_bound / 1e-4);
         out.xtris.resize(sb.leaf_order.size());
         out.tri_graze.assign(n_tri, 0);
+        // (indexed by what a path vertex keeps in Vertex::tri: the triangle id, or - in a scene with instances, where an
+        // entry is an (object, triangle) pair - the position in `stris`)
+        out.tri_xpos.assign(out.vertex_names_entry ? (uint32_t)out.stris.size() : n_tri, 0);
         for (size_t k = 0; k < sb.leaf_order.size(); k++) {
             GpuTri t = out.stris[sb.leaf_order[k]];
             const uint32_t id = (uint32_t)t.pad;
@@ -381,6 +384,7 @@ static void build_traversal_hierarchy(HostScene& out, const std::vector<Box3>& w
             std::memcpy(&bits, &graze, sizeof bits);
             t.material = (int32_t)(uint32_t)(bits >> 32) + 1;            // high word, rounded up
             out.tri_graze[id] = t.material;
+            out.tri_xpos[out.vertex_names_entry ? sb.leaf_order[k] : id] = (uint32_t)k;
             out.xtris[k] = t;
         }
     }
@@ -988,6 +992,7 @@ std::string build_instanced_pipeline(const CxHostScene& cx, HostScene& out) {
         r.tri = id;
         r.mat = (uint32_t)out.tris[id].material | ((uint32_t)m.type << 30);
     }
+    out.vertex_names_entry = !cx.objs.empty() || cx.textured || !cx.pipeline_ok;       // (what the host uploads as SceneDev::objs != null)
     build_traversal_hierarchy(out, world_box, own_box);
     out.xobj.resize(out.xtris.size());
     for (size_t k = 0; k < out.xtris.size(); k++) out.xobj[k] = out.pos_obj[(uint32_t)out.xtris[k].pad];

@@ -20,6 +20,8 @@ struct HostScene {
     std::vector<GpuTri> stris;           // triangles in leaf order (pad = original id)
     std::vector<GpuShadeRec> shade;      // per entry of `stris`: what shading a hit on it needs
     std::vector<uint32_t> tri_pos;       // per triangle: its position in `stris`
+    std::vector<uint32_t> tri_xpos;      // position in `xtris`, per triangle id (per position in `stris` when vertex_names_entry)
+    bool vertex_names_entry = false;     // the scene runs the kernels of scenes with instances: a path vertex names its entry of `stris`
     std::vector<uint32_t> tri_leaf;      // per triangle: the bvh_node that holds it
     std::vector<int32_t> tri_graze;      // per triangle: grazing threshold (high word of a double, see scene_build.cpp)
     std::vector<GpuQuadNode> xnodes;     // closest-hit hierarchy (binned SAH, four children per record)

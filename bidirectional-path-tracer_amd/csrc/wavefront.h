@@ -28,6 +28,8 @@ struct WfBuffers {
     uint32_t* conn_queue; // [ns]     samples that have both eye and light vertices
     double* contrib;      // [ns / kVtxGroup][depth][3][kVtxGroup]  what pair (a, b) of the current eye vertex a adds if its shadow ray is clear (scenes staged in LDS only)
     double* shadow;       // [8][shadow_cap]  shadow rays: origin, direction, max_t, tag (slot, b)
+    uint32_t* shadow_first;   // [shadow_cap]  position in SceneDev::xtris of the triangle a shadow ray's walk tests first (the
+                              // one its far end lies on), or null: every walk starts at the root
     uint32_t* counters;   // queue sizes and work-distribution cursors, zeroed once per batch
     const float* ray_len_ptr;  // upper bound of |direction| over the closest-hit rays: *ray_len_ptr, or ray_len when null
     float ray_len;

@@ -517,6 +517,16 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                         cur = 0;
                         leaf_left = 0;
                         sp = 0;
+                        // The far end of a shadow ray lies ON a surface at t = max_t, and in most unoccluded pairs
+                        // rounding makes that surface's own triangle accept (the reference then calls the pair
+                        // blocked, camera.h:437) - after the walk has crossed everything between the two ends.
+                        // "Some triangle accepts and is reachable" does not depend on the order of the tests, so the
+                        // walk begins as if it stood at a leaf holding that one triangle, the root waiting on the stack.
+                        if (SHADOW && wb.shadow_first) {
+                            leaf_next = wb.shadow_first[k];
+                            leaf_left = 1;
+                            push(quad_entry(true, 0.0f, 0));
+                        }
                         h.tri = -1;
                         redo = false;
                         has = true;
@@ -1038,6 +1048,8 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
                     front_face = dot(d, m.normal) < 0;
                     normal = front_face ? m.normal : neg(m.normal);
                 }
+                // (the vertex of such a scene names its entry of `stris`, not its triangle: SceneDev::tri_xpos)
+                const int32_t vertex_tri = (int32_t)pos;
                 if (TEX) {
                     const int32_t tex1 = sc.mats[m.id].pad;
                     if (tex1 > 0) {
@@ -1048,7 +1060,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
                         m.rgb = cx_texture(sc, tex1 - 1, u, v, p);
                     }
                 }
-                shade_surface<EYE, LAMBERT, MEDIA>(m, (int32_t)r.tri, p, normal, front_face, d, T, rng, bo);
+                shade_surface<EYE, LAMBERT, MEDIA>(m, vertex_tri, p, normal, front_face, d, T, rng, bo);
                 if (TEX) bo.vx.f = (m.type == 3) ? (front_face ? m.rgb : mk(0, 0, 0)) : ((m.type == 0) ? divs(m.rgb, kPi) : mk(0, 0, 0));
             } else {
                 shade_bounce_at<EYE, LAMBERT>(sc, (uint32_t)pos, o, d, t_hit, T, rng, bo);
@@ -1194,6 +1206,7 @@ __global__ __launch_bounds__(kStageBlock) void k_gen_light(SceneDev sc, GpuCamer
             else sample_emitter(sc, depth, rng, em);
             wb.ctr[slot] = rng.counter;
             if (!em.valid) continue;
+            if (sc.objs) em.ev.tri = sc.tri_pos[em.ev.tri];      // (an emitter is a triangle of the world's list: its entry of `stris`)
             slot_store(wb, slot).put<TEX>(depth, em.ev);
             if (STATS) n_stored++;
             wb.counts[slot] = cnt | (1u << 12);
@@ -1373,7 +1386,7 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
             const uint32_t p = p0 + threadIdx.x;
             bool emit = false;
             PairGeom g;
-            uint32_t slot = 0, bi = 0;
+            uint32_t slot = 0, bi = 0, lv_tri = 0;
             if (p < n_tile_pairs) {
                 uint32_t el = 0;                // the last entry whose first pair is not after p
 #pragma unroll
@@ -1382,6 +1395,7 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
                 bi = p - s_prefix[el];
                 const Vertex cv = slot_store(wb, slot).get<TEX>(a);
                 const Vertex lv = slot_store(wb, slot).get<TEX>(depth + (int)bi);
+                lv_tri = lv.tri;
                 const V3 f_cam = TEX ? cv.f : pmats.bsdf(sc, cv.info & kVtxMatMask);   // (an eye vertex on an emitter never gets here)
                 V3 f_light = mk(0, 0, 0);
                 emit = !(len2(f_cam) <= 0) && pair_geometry(cv, lv, g);                                // camera.h:458-460
@@ -1423,6 +1437,7 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
                     wb.shadow[3 * cap + e] = g.dir_unit.x; wb.shadow[4 * cap + e] = g.dir_unit.y; wb.shadow[5 * cap + e] = g.dir_unit.z;
                     wb.shadow[6 * cap + e] = g.max_t;
                     wb.shadow[7 * cap + e] = __longlong_as_double((long long)(((unsigned long long)slot << 16) | bi));
+                    if (!OWN_TEST && wb.shadow_first) wb.shadow_first[e] = sc.tri_xpos[lv_tri];
                 }
                 if (n_new > room) { chunk_next = fresh + (n_new - room); chunk_end = fresh + kShadowChunk; }
                 else chunk_next += n_new;

@@ -430,6 +430,8 @@ WF_SETTINGS = [
     {"BDPT_WF_REFILL": "1", "BDPT_WF_LEAF": "1"},
     {"BDPT_WF_REFILL": "64", "BDPT_WF_LEAF": "64"},
     {"BDPT_WF_BUDGET_GB": "1"},
+    {"BDPT_WF_NO_FIRST_LEAF": "1"},                               # shadow rays start at the root (large scenes: the default tests the far end's triangle first)
+    {"BDPT_WF_NO_FIRST_LEAF": "1", "BDPT_WF_LDS_STACK": "0"},
 ]
 
 
