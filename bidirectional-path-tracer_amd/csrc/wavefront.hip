@@ -1462,6 +1462,10 @@ __global__ __launch_bounds__(kBlock) void k_conn_accum(SceneDev sc, GpuCamera ca
         const uint32_t cnt = wb.counts[slot];
         if ((uint32_t)a >= (cnt & 0xFFFu)) continue;
         const int n_light = (int)((cnt >> 12) & 0xFFFu);
+        // most samples have no clear pair at this eye vertex: their vertex and radiance are not even read
+        unsigned long long any = 0ull;
+        for (uint32_t w = 0; w < wb.vis_words; w++) any |= wb.vis[(uint64_t)w * ns + slot];
+        if (!any) continue;
         Vertex cv;
         if (!KEPT) cv = slot_store(wb, slot).get<TEX>(a);
         V3 result = mk(wb.result[slot], wb.result[ns + slot], wb.result[2 * ns + slot]);
