@@ -1494,6 +1494,95 @@ __global__ __launch_bounds__(kBlock) void k_conn_accum(SceneDev sc, GpuCamera ca
     }
 }
 
+// The same for scenes whose clear pairs are evaluated again here (k_conn_accum<false>), one PAIR per lane.  Few samples
+// have a clear pair at a given eye vertex, so with one sample per lane nearly every wave ran the whole pair evaluation
+// for a handful of its lanes.  A wave numbers the clear pairs of its 64 samples (prefix sum of the bit counts), lane l
+// evaluates pair c0 + l whatever sample it belongs to (owner found by a search over the prefix sums, all through lane
+// shuffles), and each sample's lane then collects its own pairs' values in light-vertex order - the additions are the
+// reference's, in the reference's order.  For depths up to 64 (one word of visibility bits per sample).
+template <bool TEX>
+__global__ __launch_bounds__(kBlock) void k_conn_accum_pairs(SceneDev sc, GpuCamera cam, WfBuffers wb, int a, const uint32_t* conn_count) {
+    const uint32_t count = *conn_count;
+    const int depth = cam.max_depth;
+    const uint64_t ns = wb.ns;
+    const uint32_t lane = lane_id();
+    for (uint32_t k0 = blockIdx.x * kBlock + (threadIdx.x & ~63u); k0 < count; k0 += gridDim.x * kBlock) {     // (the same for all lanes of a wave)
+        const uint32_t k = k0 + lane;
+        uint32_t slot = 0;
+        unsigned long long bits = 0ull;
+        if (k < count) {
+            slot = wb.conn_queue[k];
+            const uint32_t cnt = wb.counts[slot];
+            if ((uint32_t)a < (cnt & 0xFFFu)) {
+                const uint32_t n_light = (cnt >> 12) & 0xFFFu;
+                bits = wb.vis[slot] & (n_light >= 64u ? ~0ull : ((1ull << n_light) - 1ull));     // a bit is set only for a pair that had a ray
+            }
+        }
+        const uint32_t np = (uint32_t)__builtin_popcountll(bits);
+        uint32_t incl = np;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if ((int)lane >= off) incl += v;
+        }
+        const uint32_t excl = incl - np;
+        const uint32_t n_pairs = __shfl(incl, 63, 64);
+        if (n_pairs == 0) continue;
+        uint32_t max_np = np;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t v = __shfl_xor(max_np, off, 64); max_np = v > max_np ? v : max_np; }
+        V3 result = mk(0, 0, 0);
+        if (np) result = mk(wb.result[slot], wb.result[ns + slot], wb.result[2 * ns + slot]);
+        bool changed = false;
+        const uint32_t bits_lo = (uint32_t)bits, bits_hi = (uint32_t)(bits >> 32);
+        for (uint32_t c0 = 0; c0 < n_pairs; c0 += 64u) {
+            const uint32_t q = c0 + lane;
+            // the sample pair q belongs to: the first lane whose inclusive sum exceeds q
+            uint32_t owner = 0;
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1) {
+                const uint32_t v = __shfl(incl, (int)(owner + step - 1u), 64);
+                if (v <= q) owner += step;
+            }
+            owner = owner > 63u ? 63u : owner;
+            const uint32_t o_excl = __shfl(excl, (int)owner, 64);
+            const uint32_t o_slot = __shfl(slot, (int)owner, 64);
+            unsigned long long o_bits = ((unsigned long long)__shfl(bits_hi, (int)owner, 64) << 32) | __shfl(bits_lo, (int)owner, 64);
+            V3 c = mk(0, 0, 0);
+            uint32_t valid = 0;
+            if (q < n_pairs) {
+                for (uint32_t r = q - o_excl; r > 0; r--) o_bits &= o_bits - 1ull;      // its (q - o_excl)-th clear pair
+                const int bi = __builtin_ctzll(o_bits);
+                const VertexStore store = slot_store(wb, o_slot);
+                const Vertex cv = store.get<TEX>(a);
+                const Vertex lv = store.get<TEX>(depth + bi);
+                PairGeom g;
+                V3 f_cam, f_light;
+                bool ok = pair_geometry(cv, lv, g);
+                if (ok) {
+                    if (TEX) {
+                        f_cam = (cv.info & kVtxIsLight) ? mk(0, 0, 0) : cv.f;
+                        f_light = lv.f;
+                        ok = !(len2(f_cam) <= 0) && len2(f_light) > 0;
+                    } else {
+                        ok = pair_factors(sc, cv, lv, f_cam, f_light);
+                    }
+                }
+                if (ok) { c = pair_contribution(cv, lv, g, f_cam, f_light); valid = 1u; }
+            }
+            // every sample's lane takes its own pairs of this round, in light-vertex order
+            for (uint32_t j = 0; j < max_np; j++) {
+                const uint32_t mine = excl + j;
+                const uint32_t src = (mine - c0) & 63u;
+                const double cx = __shfl(c.x, (int)src, 64), cy = __shfl(c.y, (int)src, 64), cz = __shfl(c.z, (int)src, 64);
+                const uint32_t v = __shfl(valid, (int)src, 64);
+                if (j < np && mine >= c0 && mine < c0 + 64u && v) { result = add(result, mk(cx, cy, cz)); changed = true; }
+            }
+        }
+        if (changed) { wb.result[slot] = result.x; wb.result[ns + slot] = result.y; wb.result[2 * ns + slot] = result.z; }
+    }
+}
+
 // per-pixel sum over the samples in the reference's order (s_j outer, s_i inner, camera.h:118-123)
 __global__ __launch_bounds__(kBlock) void k_resolve(GpuCamera cam, WfBuffers wb, WfBatch b, double* fb) {
     const int spp = cam.sqrt_spp * cam.sqrt_spp;
@@ -1881,6 +1970,8 @@ hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers
 hipError_t wf_conn_accum(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
                          const WfLaunchCfg& cfg, hipStream_t st) {
     if (cfg.own_test) hipLaunchKernelGGL((k_conn_accum<true>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
+    else if (wb.vis_words == 1 && cfg.textured) hipLaunchKernelGGL((k_conn_accum_pairs<true>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
+    else if (wb.vis_words == 1) hipLaunchKernelGGL((k_conn_accum_pairs<false>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
     else if (cfg.textured) hipLaunchKernelGGL((k_conn_accum<false, true>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
     else hipLaunchKernelGGL((k_conn_accum<false>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
     return hipGetLastError();
