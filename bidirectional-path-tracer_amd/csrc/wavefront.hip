@@ -245,10 +245,12 @@ struct TopLdsMem {
 //   |b - o|/|d| * 1.5 * 2^-23  (d to FP32 and the reciprocal)  +  |o|/|d| * 2^-23  (o to FP32 and the product)
 //   + |t| * 2^-24  (the fma)   <=   (|b| + |o|) / |d| * 0.75 * 2^-21
 // and slack = (bound + |o|) * 2^-20 * |inv| (bound = largest |coordinate| of any box) is 2.6 times that.
-// A direction component of zero (or one so small that 1/d or o/d leaves the FP32 range) would give infinities and
-// NaNs here, so such an axis is left out: inv = 0 and (c_min, c_max) = (-inf, +inf) put no bound on the interval.
+// A direction component of zero would give infinities and NaNs here; a component below 1e-30 in magnitude is taken as
+// +-1e-30 (the planes of a slab that holds o then lie at -huge and +huge, those of any other slab both at a distance
+// no interval reaches; a box within the slack of o still passes).  Should 1/d, o/d or the slack leave the FP32 range
+// all the same, the axis is left out: inv = 0 and (c_min, c_max) = (-inf, +inf) put no bound on the interval.
 // (The reference's own test, aabb.h:41-66, misses the box when the origin is outside that slab and passes
-// otherwise; leaving the axis out is the superset of both.)
+// otherwise; both treatments are supersets of it.)
 typedef float f2 __attribute__((ext_vector_type(2)));
 struct RayF32 {
     f2 inv[3];      // (1/d, 1/d)
@@ -259,7 +261,10 @@ BDPT_DEV RayF32 ray_f32(V3 o, V3 d, float bound) {
     const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const float inv = __builtin_amdgcn_rcpf((float)dd[a]);
+        // (leaving the axis out instead sends a ray that runs inside an axis-parallel plane - two points of one floor
+        // with exactly equal heights - through every box above and below it: 20 x the time for such query segments)
+        const float d32 = (float)dd[a];
+        const float inv = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d32), 1e-30f), d32));
         const float of = (float)oo[a];
         const float c = -(of * inv);
         const float slack = (bound + __builtin_fabsf(of)) * 0x1p-20f * __builtin_fabsf(inv) * 1.000001f;

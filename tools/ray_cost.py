@@ -1,0 +1,39 @@
+"""The same segments between random surface points once as visibility queries (any hit) and once as closest-hit rays,
+through the pipeline's traversal kernels: run under rocprofv3 --kernel-trace --stats and compare k_traverse<true, ...>
+with k_traverse<false, ...>.   python tools/ray_cost.py [lattice|coffee] [n]"""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+capi = importlib.import_module("bidirectional-path-tracer_amd.capi")
+scenes = importlib.import_module("bidirectional-path-tracer_amd.scenes")
+which = sys.argv[1] if len(sys.argv) > 1 else "lattice"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 21
+flat = scenes.sphere_lattice(10, 64, 4, 4) if which == "lattice" else scenes.coffee_machine_standin(64, 36, 4, 4)
+ctx = capi.Context(0)
+sc = ctx.scene(flat)
+v = flat.vertex_array().reshape(-1, 3)
+lo, hi = v.min(axis=0), v.max(axis=0)
+rng = np.random.default_rng(1)
+o = rng.uniform(lo, hi, (2 * n, 3))
+t = rng.uniform(lo, hi, (2 * n, 3))
+rays = np.concatenate([o, t - o, np.full((2 * n, 1), 0.001), np.full((2 * n, 1), np.inf)], axis=1)
+hits = sc.trace_closest(rays)
+pts = hits[hits[:, 0] >= 0][:, 5:8]
+a, b = pts[rng.integers(0, len(pts), n)], pts[rng.integers(0, len(pts), n)]
+pairs = np.concatenate([a, b], axis=1)
+vis = sc.visible(pairs)
+d = b - a
+dist = np.sqrt((d * d).sum(axis=1))
+ok = dist > 0.01
+u = d[ok] / dist[ok, None]
+seg = np.concatenate([a[ok] + 0.001 * u, u, np.full((ok.sum(), 1), 0.001), (dist[ok] - 0.001)[:, None]], axis=1)
+h2 = sc.trace_closest(seg)
+# the same segments cut off half way (no surface at the far end), and as closest-hit rays with an open end
+mid = np.concatenate([a, a + 0.5 * d], axis=1)
+vis_mid = sc.visible(mid)
+seg_inf = seg.copy(); seg_inf[:, 7] = np.inf
+h3 = sc.trace_closest(seg_inf)
+print("order of traversal launches: closest(random rays), visibility(segments), closest(segments), visibility(half segments), closest(open rays)")
+print("visible half segments", int(vis_mid.sum()))
+print(which, "segments", n, "visible", int(vis.sum()), "closest-hit finds something on", int((h2[:, 0] >= 0).sum()), "of", len(seg))
