@@ -382,7 +382,26 @@ static void build_traversal_hierarchy(HostScene& out, const std::vector<Box3>& w
             if (thin_axes >= 2 || !(graze == graze)) graze = std::numeric_limits<double>::infinity();
             uint64_t bits;
             std::memcpy(&bits, &graze, sizeof bits);
-            t.material = (int32_t)(uint32_t)(bits >> 32) + 1;            // high word, rounded up
+            // Which faces of the reference's boxes above the triangle lie (almost) in the triangle's own plane: bit
+            // 2a for the lower face on axis a, 2a + 1 for the upper one.  A visibility ray that ends on the triangle
+            // meets such a box at the very end of its interval, where rounding decides whether the reference gets to test
+            // the triangle at all (aabb.h:56-63) - but only if it ENTERS the box through that face.  The triangle's own
+            // box is not padded (triangle.h:38 builds it from two points); a bvh_node's is when it is thin
+            // (aabb.h:26-32,81-88), so the boxes above a flat triangle come within 5e-5 of its plane or coincide with
+            // it.  On an axis where the triangle is not thin, a hit away from its outline lies inside every box above it
+            // by the margin of wavefront.hip's exact rule: no bit.  An entry of a scene with instances: all bits.
+            uint32_t faces = out.vertex_names_entry ? 63u : 0u;
+            if (!out.vertex_names_entry && thin_axes > 0) {
+                const Box3& tb = own_box[sb.leaf_order[k]];
+                for (uint32_t n = out.sleaf[sb.leaf_order[k]] & 0x7FFFFFFFu; n != kEndOfTree; n = out.node_parent[n])
+                    for (int a = 0; a < 3; a++) {
+                        if (!(tb.hi[a] - tb.lo[a] < 1e-4)) continue;
+                        if (!(tb.lo[a] - out.nodes[n].lo[a] >= 1e-5)) faces |= 1u << (2 * a);
+                        if (!(out.nodes[n].hi[a] - tb.hi[a] >= 1e-5)) faces |= 2u << (2 * a);
+                    }
+            }
+            // high word of the threshold, rounded up to a multiple of 64; the face bits ride in the six bits below
+            t.material = (int32_t)((((uint32_t)(bits >> 32) + 1u + 63u) & ~63u) | faces);
             out.tri_graze[id] = t.material;
             out.tri_xpos[out.vertex_names_entry ? sb.leaf_order[k] : id] = (uint32_t)k;
             out.xtris[k] = t;

@@ -208,6 +208,18 @@ BDPT_DEV bool grazes(const GpuTri& tr, double u, double v, double t, double det,
 }
 // |hi(a) - hi(b)| <= 1 for positive a, b (+infinity included)
 BDPT_DEV bool nearly_equal(double a, double b) { return (hi32(a) - hi32(b) + 1u) <= 2u; }
+// The low six bits of that field name the faces of the reference's boxes above the triangle that lie in the triangle's
+// own plane (scene_build.cpp).  A visibility ray that ends ON the triangle (t = max_t up to rounding) is let through by
+// all those boxes unless it enters one of them through such a face: bit 2a when it travels upwards on axis a, bit
+// 2a + 1 when downwards.  A component of exactly zero (the reference's arithmetic then works with infinities and
+// NaNs) answers "any".
+BDPT_DEV bool ends_on_box_face(const GpuTri& tr, V3 d) {
+    const uint32_t sx = hi32(d.x), sy = hi32(d.y), sz = hi32(d.z);
+    const uint32_t entered = (1u + (sx >> 31)) | ((1u + (sy >> 31)) << 2) | ((1u + (sz >> 31)) << 4);
+    const uint32_t e = 0x7FF00000u;
+    const bool some_zero = ((sx & e) == 0u) | ((sy & e) == 0u) | ((sz & e) == 0u);
+    return (((uint32_t)tr.material & entered) != 0u) | some_zero;
+}
 
 constexpr int kQuadStackDepth = kQuadStackEntries;
 constexpr int32_t kPop = (int32_t)0x80000000;   // neither an interior index (>= 0) nor a leaf reference
@@ -614,7 +626,8 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                         // accepted triangle contain the hit point with a margin, so they pass; a hit at the far end
                         // (the far end point's own surface, t = max_t up to rounding: most unoccluded pairs) or a
                         // grazing one counts only if the reference's own boxes let it through.
-                        const bool check = nearly_equal(t, closest) || grazes(tr, u, v, t, det, gbits);
+                        // (td: the ray as the triangle's own boxes see it)
+                        const bool check = (nearly_equal(t, closest) && ends_on_box_face(tr, td)) || grazes(tr, u, v, t, det, gbits);
                         if (!check || ref.reaches(sc, INSTANCED ? (uint32_t)tr.pad : sc.sleaf[tr.pad], o, d, closest)) { h.tri = tr.pad; done = true; leaf_left = 0; }
                     }
                 } else {
@@ -1410,7 +1423,7 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
                     own.material = own_graze[lv.tri];
                     double t, u, v, det;
                     if (tri_candidate(own, g.origin, g.dir_unit, 0.001, t, u, v, det) && t <= g.max_t) {
-                        const bool check = nearly_equal(t, g.max_t) || grazes(own, u, v, t, det, gbits);
+                        const bool check = (nearly_equal(t, g.max_t) && ends_on_box_face(own, g.dir_unit)) || grazes(own, u, v, t, det, gbits);
                         if (!check || reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t)) emit = false;
                     }
                 }

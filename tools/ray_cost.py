@@ -32,8 +32,10 @@ h2 = sc.trace_closest(seg)
 # the same segments cut off half way (no surface at the far end), and as closest-hit rays with an open end
 mid = np.concatenate([a, a + 0.5 * d], axis=1)
 vis_mid = sc.visible(mid)
+near_end = np.concatenate([a, a + 0.99 * d], axis=1)          # the far end just in front of its surface
+vis_near = sc.visible(near_end)
 seg_inf = seg.copy(); seg_inf[:, 7] = np.inf
 h3 = sc.trace_closest(seg_inf)
-print("order of traversal launches: closest(random rays), visibility(segments), closest(segments), visibility(half segments), closest(open rays)")
-print("visible half segments", int(vis_mid.sum()))
+print("order of traversal launches: closest(random rays), visibility(segments), closest(segments), visibility(half segments), visibility(99 % segments), closest(open rays)")
+print("visible half segments", int(vis_mid.sum()), "visible 99 % segments", int(vis_near.sum()))
 print(which, "segments", n, "visible", int(vis.sum()), "closest-hit finds something on", int((h2[:, 0] >= 0).sum()), "of", len(seg))

@@ -1,0 +1,24 @@
+import importlib, os, sys, ctypes as C
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+import numpy as np
+capi = importlib.import_module("bidirectional-path-tracer_amd.capi")
+scenes = importlib.import_module("bidirectional-path-tracer_amd.scenes")
+from conftest import composite_scene
+ctx = capi.Context(0)
+lib = ctx.lib
+def counts():
+    out = (C.c_ulonglong * 8)()
+    lib.bdpt_debug_reach_counts(out)
+    return np.array(list(out), dtype=np.int64)
+prev = counts()
+cases = [("cornell", scenes.cornell_box(256, 64, 10)), ("coplanar", scenes.coplanar_stack(128, 64, 6)), ("mixed3k", scenes.mixed_materials_3k(160, 64, 8)),
+         ("showcase", scenes.materials_showcase(160, 64, 8)), ("lattice1m", scenes.sphere_lattice(10, 256, 16, 10)),
+         ("coffee", scenes.coffee_machine_standin(480, 270, 16, 10)), ("cx_instances", composite_scene(scenes, "cx_instances")[0]),
+         ("lattice_inst", scenes.sphere_lattice_instanced(6, 128, 16, 10))]
+for name, flat in cases:
+    sc = ctx.scene(flat)
+    cam = capi.camera_initialize(flat.camera)
+    sc.render(cam, seed=5)
+    now = counts(); dlt = now - prev; prev = now
+    print("%-12s traversal: ties not through a plane face %10d of them unreached %6d | through one %9d unreached %8d || conn_gen: not through %10d unreached %6d | through %9d unreached %8d" % (name, *dlt), flush=True)
+    sc.close()
