@@ -65,6 +65,7 @@ struct Knobs {
     int leaf_inner;       // 0: half the leaf threshold
     int chunk;
     int no_first_leaf;    // 1: shadow rays start at the root like all others
+    int first_leaf_mb;    // largest triangle table (MB) whose shadow rays test their far end's triangle first
 };
 
 Knobs read_knobs() {
@@ -80,6 +81,7 @@ Knobs read_knobs() {
     k.leaf_inner = env_int("BDPT_WF_LEAF_INNER", 0, 0, 64);
     k.chunk = env_int("BDPT_WF_CHUNK", 512, 1, 1 << 20);
     k.no_first_leaf = env_int("BDPT_WF_NO_FIRST_LEAF", 0, 0, 1);
+    k.first_leaf_mb = env_int("BDPT_WF_FIRST_LEAF_MB", 1 << 20, 0, 1 << 20);
     return k;
 }
 
@@ -336,11 +338,10 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     if (n_owned >= ((int64_t)1 << 31)) return fail(BDPT_ERR_UNSUPPORTED, "more than 2^31 pixels in one call");
     // bytes of state per sample slot
     // A shadow ray of a scene too large for LDS first tests the triangle its far end lies on (WfBuffers::shadow_first, a
-    // ninth, 32-bit word per ray): +17 % on the 51 k-triangle coffee machine, +9 % on a 0.96 M-triangle lattice.  That
-    // test is one access to a random place of the triangle table, so it pays while the table stays in the 256 MB
-    // last-level cache: on 10.2 M triangles (0.8 GB) it is an HBM round trip per ray and costs 8 %.
+    // ninth, 32-bit word per ray): +17 % on the 51 k-triangle coffee machine, +9 % on a 0.96 M-triangle lattice, +15 % on
+    // 10.2 M triangles.  (BDPT_WF_FIRST_LEAF_MB limits it to triangle tables up to that size.)
     const bool first_leaf = !cfg.lds_scene && !cfg.ordered && scene->dev.tri_xpos != nullptr &&
-                            scene->host.xtris.size() * sizeof(GpuTri) <= ((size_t)256 << 20) && !ctx->knobs.no_first_leaf;
+                            scene->host.xtris.size() * sizeof(GpuTri) <= ((size_t)ctx->knobs.first_leaf_mb << 20) && !ctx->knobs.no_first_leaf;
     const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 6 + vslots * rec_doubles * sizeof(double) +
                             vis_words * sizeof(unsigned long long) + (shadow_per_slot * 8 + kept_per_slot * 3) * sizeof(double) +
                             (first_leaf ? shadow_per_slot * 4 : 0) +

@@ -390,7 +390,11 @@ static void build_traversal_hierarchy(HostScene& out, const std::vector<Box3>& w
             // (aabb.h:26-32,81-88), so the boxes above a flat triangle come within 5e-5 of its plane or coincide with
             // it.  On an axis where the triangle is not thin, a hit away from its outline lies inside every box above it
             // by the margin of wavefront.hip's exact rule: no bit.  An entry of a scene with instances: all bits.
-            uint32_t faces = out.vertex_names_entry ? 63u : 0u;
+            // (there the chain runs through the mesh's boxes in the mesh's coordinates and through the world's in the
+            // world's: an entry whose triangle is thin in neither has no such face, any other keeps all bits)
+            int thin_world = 0;
+            for (int a = 0; a < 3; a++) thin_world += (world_box[sb.leaf_order[k]].hi[a] - world_box[sb.leaf_order[k]].lo[a] < 1e-4) ? 1 : 0;
+            uint32_t faces = (out.vertex_names_entry && (thin_axes > 0 || thin_world > 0)) ? 63u : 0u;
             if (!out.vertex_names_entry && thin_axes > 0) {
                 const Box3& tb = own_box[sb.leaf_order[k]];
                 for (uint32_t n = out.sleaf[sb.leaf_order[k]] & 0x7FFFFFFFu; n != kEndOfTree; n = out.node_parent[n])
