@@ -395,17 +395,29 @@ static void build_traversal_hierarchy(HostScene& out, const std::vector<Box3>& w
             int thin_world = 0;
             for (int a = 0; a < 3; a++) thin_world += (world_box[sb.leaf_order[k]].hi[a] - world_box[sb.leaf_order[k]].lo[a] < 1e-4) ? 1 : 0;
             uint32_t faces = (out.vertex_names_entry && (thin_axes > 0 || thin_world > 0)) ? 63u : 0u;
+            // ... and on which sides every such face lies EXACTLY in the plane of an exactly flat triangle: the plane's
+            // coordinate is then the triangle's own, all those boxes give the same distance to it, and the kernels
+            // settle the tie with the one product of aabb.h:49-50 that decides it
+            uint32_t inexact = 0u;
             if (!out.vertex_names_entry && thin_axes > 0) {
                 const Box3& tb = own_box[sb.leaf_order[k]];
-                for (uint32_t n = out.sleaf[sb.leaf_order[k]] & 0x7FFFFFFFu; n != kEndOfTree; n = out.node_parent[n])
+                // (boxes that contain one another: the one next to the triangle decides, as in reference_reaches)
+                for (uint32_t n = out.sleaf[sb.leaf_order[k]] & 0x7FFFFFFFu; n != kEndOfTree; n = out.ref_nested ? kEndOfTree : out.node_parent[n])
                     for (int a = 0; a < 3; a++) {
                         if (!(tb.hi[a] - tb.lo[a] < 1e-4)) continue;
-                        if (!(tb.lo[a] - out.nodes[n].lo[a] >= 1e-5)) faces |= 1u << (2 * a);
-                        if (!(out.nodes[n].hi[a] - tb.hi[a] >= 1e-5)) faces |= 2u << (2 * a);
+                        const bool flat = tb.lo[a] == tb.hi[a];
+                        if (!(tb.lo[a] - out.nodes[n].lo[a] >= 1e-5)) {
+                            faces |= 1u << (2 * a);
+                            if (!(flat && out.nodes[n].lo[a] == tb.lo[a])) inexact |= 1u << (2 * a);
+                        }
+                        if (!(out.nodes[n].hi[a] - tb.hi[a] >= 1e-5)) {
+                            faces |= 2u << (2 * a);
+                            if (!(flat && out.nodes[n].hi[a] == tb.hi[a])) inexact |= 2u << (2 * a);
+                        }
                     }
             }
-            // high word of the threshold, rounded up to a multiple of 64; the face bits ride in the six bits below
-            t.material = (int32_t)((((uint32_t)(bits >> 32) + 1u + 63u) & ~63u) | faces);
+            // high word of the threshold, rounded up to a multiple of 4096; the face bits ride in the twelve bits below
+            t.material = (int32_t)((((uint32_t)(bits >> 32) + 1u + 4095u) & ~4095u) | ((faces & ~inexact) << 6) | faces);
             out.tri_graze[id] = t.material;
             out.tri_xpos[out.vertex_names_entry ? sb.leaf_order[k] : id] = (uint32_t)k;
             out.xtris[k] = t;

@@ -211,14 +211,33 @@ BDPT_DEV bool nearly_equal(double a, double b) { return (hi32(a) - hi32(b) + 1u)
 // The low six bits of that field name the faces of the reference's boxes above the triangle that lie in the triangle's
 // own plane (scene_build.cpp).  A visibility ray that ends ON the triangle (t = max_t up to rounding) is let through by
 // all those boxes unless it enters one of them through such a face: bit 2a when it travels upwards on axis a, bit
-// 2a + 1 when downwards.  A component of exactly zero (the reference's arithmetic then works with infinities and
-// NaNs) answers "any".
-BDPT_DEV bool ends_on_box_face(const GpuTri& tr, V3 d) {
+// 2a + 1 when downwards.  With a component of exactly zero the reference's arithmetic works with infinities and
+// NaNs: its boxes are asked.
+// Six more bits (6..11) mark the sides on which all those faces lie exactly in the plane of an exactly flat triangle.
+// Such a tie is settled here: every other plane of every box above the triangle is passed with a margin, so aabb::hit
+// (aabb.h:45-62) comes down, for each of them alike, to whether the distance to that plane, formed as the reference
+// forms it, leaves anything of the interval.
+// Returns 0: the reference gets to test the triangle; 1: it does not; 2: its boxes have to be asked.
+// (EXACT = false: a scene with instances, whose entries carry no such marks)
+template <bool EXACT>
+BDPT_DEV int far_end_tie(const GpuTri& tr, V3 o, V3 d, double max_t) {
     const uint32_t sx = hi32(d.x), sy = hi32(d.y), sz = hi32(d.z);
     const uint32_t entered = (1u + (sx >> 31)) | ((1u + (sy >> 31)) << 2) | ((1u + (sz >> 31)) << 4);
     const uint32_t e = 0x7FF00000u;
     const bool some_zero = ((sx & e) == 0u) | ((sy & e) == 0u) | ((sz & e) == 0u);
-    return (((uint32_t)tr.material & entered) != 0u) | some_zero;
+    const uint32_t faces = (uint32_t)tr.material & entered;
+    if (some_zero) return 2;
+    if (faces == 0u) return 0;
+    if (!EXACT) return 2;
+    const uint32_t exact = ((uint32_t)tr.material >> 6) & entered;
+    if (exact != faces || (faces & (faces - 1u)) != 0u) return 2;          // (one face, and that one exact)
+    const int axis = (faces & 3u) ? 0 : ((faces & 12u) ? 1 : 2);
+    const double plane = axis == 0 ? tr.v0[0] : (axis == 1 ? tr.v0[1] : tr.v0[2]);      // (a flat triangle: all its points share it)
+    const double oa = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
+    const double da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+    const double adinv = 1.0 / da;                                          // aabb.h:47
+    const double t_face = (plane - oa) * adinv;                             // aabb.h:49-50
+    return (max_t <= t_face) ? 1 : 0;                                       // aabb.h:60-61
 }
 
 constexpr int kQuadStackDepth = kQuadStackEntries;
@@ -626,9 +645,10 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                         // accepted triangle contain the hit point with a margin, so they pass; a hit at the far end
                         // (the far end point's own surface, t = max_t up to rounding: most unoccluded pairs) or a
                         // grazing one counts only if the reference's own boxes let it through.
-                        // (td: the ray as the triangle's own boxes see it)
-                        const bool check = (nearly_equal(t, closest) && ends_on_box_face(tr, td)) || grazes(tr, u, v, t, det, gbits);
-                        if (!check || ref.reaches(sc, INSTANCED ? (uint32_t)tr.pad : sc.sleaf[tr.pad], o, d, closest)) { h.tri = tr.pad; done = true; leaf_left = 0; }
+                        // (to, td: the ray as the triangle's own boxes see it)
+                        int ask = grazes(tr, u, v, t, det, gbits) ? 2 : (nearly_equal(t, closest) ? far_end_tie<!INSTANCED>(tr, to, td, closest) : 0);
+                        if (ask == 2) ask = ref.reaches(sc, INSTANCED ? (uint32_t)tr.pad : sc.sleaf[tr.pad], o, d, closest) ? 0 : 1;
+                        if (ask == 0) { h.tri = tr.pad; done = true; leaf_left = 0; }
                     }
                 } else {
                     // (the walk goes on after an exact tie: rare, and the loop keeps its shape - no branch here)
@@ -1423,8 +1443,9 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
                     own.material = own_graze[lv.tri];
                     double t, u, v, det;
                     if (tri_candidate(own, g.origin, g.dir_unit, 0.001, t, u, v, det) && t <= g.max_t) {
-                        const bool check = (nearly_equal(t, g.max_t) && ends_on_box_face(own, g.dir_unit)) || grazes(own, u, v, t, det, gbits);
-                        if (!check || reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t)) emit = false;
+                        int ask = grazes(own, u, v, t, det, gbits) ? 2 : (nearly_equal(t, g.max_t) ? far_end_tie<true>(own, g.origin, g.dir_unit, g.max_t) : 0);
+                        if (ask == 2) ask = reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t) ? 0 : 1;
+                        if (ask == 0) emit = false;
                     }
                 }
                 if (OWN_TEST && emit) {

@@ -20,5 +20,5 @@ for name, flat in cases:
     cam = capi.camera_initialize(flat.camera)
     sc.render(cam, seed=5)
     now = counts(); dlt = now - prev; prev = now
-    print("%-12s traversal: ties not through a plane face %10d of them unreached %6d | through one %9d unreached %8d || conn_gen: not through %10d unreached %6d | through %9d unreached %8d" % (name, *dlt), flush=True)
+    print("%-12s traversal: ties settled without the boxes, triangles without exact faces %10d wrong %4d | with %9d wrong %4d || conn_gen: without %10d wrong %4d | with %9d wrong %4d" % (name, *dlt), flush=True)
     sc.close()
