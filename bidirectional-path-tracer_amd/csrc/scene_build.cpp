@@ -390,16 +390,17 @@ static void build_traversal_hierarchy(HostScene& out, const std::vector<Box3>& w
             // (aabb.h:26-32,81-88), so the boxes above a flat triangle come within 5e-5 of its plane or coincide with
             // it.  On an axis where the triangle is not thin, a hit away from its outline lies inside every box above it
             // by the margin of wavefront.hip's exact rule: no bit.  An entry of a scene with instances: all bits.
-            // (there the chain runs through the mesh's boxes in the mesh's coordinates and through the world's in the
-            // world's: an entry whose triangle is thin in neither has no such face, any other keeps all bits)
+            // (an entry that belongs to an object: the chain runs through the mesh's boxes in the mesh's coordinates and
+            // through the world's in the world's; thin in neither, it has no such face, otherwise it keeps all bits)
+            const bool in_object = out.vertex_names_entry && out.pos_obj[sb.leaf_order[k]] >= 0;
             int thin_world = 0;
             for (int a = 0; a < 3; a++) thin_world += (world_box[sb.leaf_order[k]].hi[a] - world_box[sb.leaf_order[k]].lo[a] < 1e-4) ? 1 : 0;
-            uint32_t faces = (out.vertex_names_entry && (thin_axes > 0 || thin_world > 0)) ? 63u : 0u;
+            uint32_t faces = (in_object && (thin_axes > 0 || thin_world > 0)) ? 63u : 0u;
             // ... and on which sides every such face lies EXACTLY in the plane of an exactly flat triangle: the plane's
             // coordinate is then the triangle's own, all those boxes give the same distance to it, and the kernels
             // settle the tie with the one product of aabb.h:49-50 that decides it
             uint32_t inexact = 0u;
-            if (!out.vertex_names_entry && thin_axes > 0) {
+            if (!in_object && thin_axes > 0) {
                 const Box3& tb = own_box[sb.leaf_order[k]];
                 // (boxes that contain one another: the one next to the triangle decides, as in reference_reaches)
                 for (uint32_t n = out.sleaf[sb.leaf_order[k]] & 0x7FFFFFFFu; n != kEndOfTree; n = out.ref_nested ? kEndOfTree : out.node_parent[n])

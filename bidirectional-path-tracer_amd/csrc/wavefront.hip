@@ -218,7 +218,6 @@ BDPT_DEV bool nearly_equal(double a, double b) { return (hi32(a) - hi32(b) + 1u)
 // (aabb.h:45-62) comes down, for each of them alike, to whether the distance to that plane, formed as the reference
 // forms it, leaves anything of the interval.
 // Returns 0: the reference gets to test the triangle; 1: it does not; 2: its boxes have to be asked.
-// (EXACT = false: a scene with instances, whose entries carry no such marks)
 template <bool EXACT>
 BDPT_DEV int far_end_tie(const GpuTri& tr, V3 o, V3 d, double max_t) {
     const uint32_t sx = hi32(d.x), sy = hi32(d.y), sz = hi32(d.z);
@@ -646,7 +645,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                         // (the far end point's own surface, t = max_t up to rounding: most unoccluded pairs) or a
                         // grazing one counts only if the reference's own boxes let it through.
                         // (to, td: the ray as the triangle's own boxes see it)
-                        int ask = grazes(tr, u, v, t, det, gbits) ? 2 : (nearly_equal(t, closest) ? far_end_tie<!INSTANCED>(tr, to, td, closest) : 0);
+                        int ask = grazes(tr, u, v, t, det, gbits) ? 2 : (nearly_equal(t, closest) ? far_end_tie<true>(tr, to, td, closest) : 0);
                         if (ask == 2) ask = ref.reaches(sc, INSTANCED ? (uint32_t)tr.pad : sc.sleaf[tr.pad], o, d, closest) ? 0 : 1;
                         if (ask == 0) { h.tri = tr.pad; done = true; leaf_left = 0; }
                     }
