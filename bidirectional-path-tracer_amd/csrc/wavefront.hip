@@ -802,12 +802,12 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
 
 // Triangle id (or -1) and distance of the closest hit the traversal kernel recorded for `slot`; a ray it marked
 // kHitRedo is traced here with the reference's own traversal (bvh_node::hit over the reference's tree).
-__device__ __attribute__((noinline)) int32_t redo_closest(const SceneDev& sc, V3 o, V3 d, double tmax, double& t) {
+__device__ __attribute__((noinline)) int32_t redo_closest(const SceneDev& sc, V3 o, V3 d, double tmin, double tmax, double& t) {
     GlobalScene mem{sc.nodes, sc.tris};
     Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     HitLite h;
     h.tri = -1; h.t = 0; h.u = 0; h.v = 0;
-    if (!walk<kStatsOff, false>(mem, o, d, 0.001, tmax, h, c)) return -1;
+    if (!walk<kStatsOff, false>(mem, o, d, tmin, tmax, h, c)) return -1;
     t = h.t;
     return h.tri;
 }
@@ -863,20 +863,26 @@ __global__ __launch_bounds__(kBlock) void k_redo(SceneDev sc, WfBuffers wb, cons
         // IS the reference's; the walk over the unordered median-split tree, which otherwise wanders through
         // everything the ray's line meets, stays near the hit.  Nothing found (the triangle the kernel saw is one the
         // reference does not reach): once more with the interval as it was.
+        // The first walk's interval also BEGINS just in front of that distance: the traversal kernel has tested every
+        // triangle on the ray that the reference could accept, and none lies nearer than what it found, so the
+        // reference accepts nothing in front of the cut either; a box that holds one of the triangles in question
+        // reaches into the shortened interval and is passed or missed as before, the others are not looked into.
         const double hint = wb.hit[slot];
         // (distances that tie lie within 2^-19 of each other; a hit distance is good to ~1e-6 of itself even for a ray
         // that meets its triangle at the reference's smallest accepted determinant)
         const double bound = hint * 1.0009765625;                          // 1 + 2^-10
+        const double from = __builtin_fmax(0.001, hint * 0.9990234375);    // 1 - 2^-10
         int32_t pos = -1;
         double t = 0.0;
         for (int pass = (bound < tmax) ? 0 : 1; pass < 2 && pos < 0; pass++) {
             const double upto = pass == 0 ? bound : tmax;
+            const double lower = pass == 0 ? from : 0.001;
             if (INSTANCED) {
                 CxHit rh;
-                pos = redo_closest_instanced(sc, o, d, 0.001, upto, rh);
+                pos = redo_closest_instanced(sc, o, d, lower, upto, rh);
                 t = rh.t;
             } else {
-                const int32_t tri = redo_closest(sc, o, d, upto, t);
+                const int32_t tri = redo_closest(sc, o, d, lower, upto, t);
                 pos = tri < 0 ? -1 : (int32_t)sc.tri_pos[tri];
             }
         }
