@@ -1,3 +1,9 @@
+"""Counts kept by a library INSTRUMENTED for it (not the shipped one): in the two places where a far-end tie is decided
+(traverse_queue's visibility branch, k_conn_gen's own-triangle test) the instrumented build also runs the walk over the
+reference's boxes and adds to a device array g_reach[8] - [0]/[4] ties settled without the boxes on triangles without
+exact-face bits, [1]/[5] how many of those the walk decides differently, [2]/[3] and [6]/[7] the same for triangles
+with such bits - read back through an exported bdpt_debug_reach_counts(unsigned long long out[8]).
+    BDPT_LIB=<instrumented .so> python tools/reach_count.py"""
 import importlib, os, sys, ctypes as C
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 import numpy as np
