@@ -101,7 +101,7 @@ EXPORTED_SYMBOLS = [
     "bdpt_colors_to_rgb8", "bdpt_colors_to_rgb8_device", "bdpt_device_sincos", "bdpt_device_random_doubles",
     "bdpt_device_arith", "bdpt_scene_file_load", "bdpt_scene_file_destroy", "bdpt_scene_file_get", "bdpt_write_png", "bdpt_debug_yaml_to_json",
     "bdpt_reduce_framebuffer", "bdpt_context_set_workspace_limit", "bdpt_context_set_query_walker",
-    "bdpt_render_device_static", "bdpt_scene_create_composite",
+    "bdpt_render_device_static", "bdpt_scene_create_composite", "bdpt_debug_tie_counts",
 ]
 
 WALKER_PIPELINE = 0          # traversal kernels of the render pipeline (default)
@@ -160,6 +160,7 @@ def load_library() -> C.CDLL:
     lib.bdpt_debug_yaml_to_json.argtypes = [C.c_char_p, C.c_char_p, u64]
     lib.bdpt_context_set_workspace_limit.argtypes = [vp, u64]
     lib.bdpt_context_set_query_walker.argtypes = [vp, C.c_int]
+    lib.bdpt_debug_tie_counts.argtypes = [vp, vp, C.c_int]
     for name in EXPORTED_SYMBOLS:
         if name != "bdpt_last_error":
             getattr(lib, name).restype = C.c_int
@@ -275,6 +276,15 @@ class Context:
         _check(self.lib.bdpt_context_set_query_walker(self.h, int(walker)))
 
     # -- test hooks ---------------------------------------------------------------
+    TIE_COUNT_NAMES = ("ties", "settled_by_face_bits", "settled_by_exact_plane", "left_to_boxes", "wrong_by_face_bits",
+                       "wrong_by_exact_plane", "plain_hits", "plain_hits_unreached")
+
+    def tie_counts(self, reset: bool = False) -> dict:
+        """Counters of the cross-check build (BDPT_LIB=.../libbdpt_amd_tiecheck.so); raises BdptError on the normal one."""
+        o = np.zeros(8, dtype=np.uint64)
+        _check(self.lib.bdpt_debug_tie_counts(self.h, _ptr(o), 1 if reset else 0))
+        return {n: int(v) for n, v in zip(self.TIE_COUNT_NAMES, o)}
+
     def device_sincos(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         s, c = np.zeros_like(x), np.zeros_like(x)

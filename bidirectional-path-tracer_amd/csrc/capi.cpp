@@ -66,6 +66,7 @@ struct Knobs {
     int chunk;
     int no_first_leaf;    // 1: shadow rays start at the root like all others
     int first_leaf_mb;    // largest triangle table (MB) whose shadow rays test their far end's triangle first
+    int redo_blocks;      // workgroups of k_redo; 0: eight per compute unit
 };
 
 Knobs read_knobs() {
@@ -82,6 +83,7 @@ Knobs read_knobs() {
     k.chunk = env_int("BDPT_WF_CHUNK", 512, 1, 1 << 20);
     k.no_first_leaf = env_int("BDPT_WF_NO_FIRST_LEAF", 0, 0, 1);
     k.first_leaf_mb = env_int("BDPT_WF_FIRST_LEAF_MB", 1 << 20, 0, 1 << 20);
+    k.redo_blocks = env_int("BDPT_WF_REDO_BLOCKS", 0, 0, 1 << 16);
     return k;
 }
 
@@ -299,7 +301,10 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     cfg.leaf_inner = kn.leaf_inner > 0 ? kn.leaf_inner : (cfg.leaf_threshold > 1 ? cfg.leaf_threshold / 2 : 1);
     cfg.chunk = (uint32_t)kn.chunk;   // measured: the cursor is one address, and its atomics cost more than a coarser split
     cfg.stream_blocks = ctx->cu_count * 8;
-    cfg.redo_blocks = ctx->cu_count * 8;
+    // (one workgroup per compute unit: the list is short - a few rays in 10^5 - and every workgroup of the launch has to find a
+    // place beside the resident traversal waves of the other batches before the stream can go on; eight per unit cost the
+    // coffee machine 4 % of its frame)
+    cfg.redo_blocks = kn.redo_blocks > 0 ? kn.redo_blocks : ctx->cu_count;
     return BDPT_OK;
 }
 
@@ -1333,6 +1338,18 @@ int bdpt_device_random_doubles(bdpt_context* ctx, uint64_t seed, uint64_t pixel,
 int bdpt_device_arith(bdpt_context* ctx, int op, const double* a, const double* b, uint64_t n, double* out) {
     if (n && (!a || !b || !out)) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
     return run_unary(ctx, 2, op, a, b, n, out, nullptr, 0, 0, 0);
+}
+
+int bdpt_debug_tie_counts(bdpt_context* ctx, uint64_t* out8, int reset) {
+    if (!ctx || !out8) return fail(BDPT_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long c[8];
+    const hipError_t e = wf_tie_counts(c, reset != 0);
+    if (e == hipErrorNotSupported) return fail(BDPT_ERR_UNSUPPORTED, "this build does not cross-check far-end ties (build the `tiecheck` variant)");
+    if (e != hipSuccess) return hip_fail(e, "wf_tie_counts");
+    for (int k = 0; k < 8; k++) out8[k] = c[k];
+    return BDPT_OK;
 }
 
 }  // extern "C"

@@ -125,6 +125,10 @@ hipError_t wf_conn_accum(const SceneDev& sc, const GpuCamera& cam, const WfBuffe
 hipError_t wf_resolve(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, double* fb, const WfLaunchCfg& cfg,
                       hipStream_t st);
 
+// Cross-check build only (-DBDPT_TIE_CHECK): the eight counters of the comparison between the in-place settling of
+// far-end ties and the reference's own box walk (see g_tie_counts in wavefront.hip); hipErrorNotSupported otherwise.
+hipError_t wf_tie_counts(unsigned long long* out8, bool reset);
+
 // sets the LDS limit of the traversal kernels for this launch shape and reports how many workgroups fit a CU
 hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu);
 

@@ -239,6 +239,35 @@ BDPT_DEV int far_end_tie(const GpuTri& tr, V3 o, V3 d, double max_t) {
     return (max_t <= t_face) ? 1 : 0;                                       // aabb.h:60-61
 }
 
+#ifdef BDPT_TIE_CHECK
+// Cross-check build (make tiecheck): every accepted hit of a visibility ray that is not a grazing one is ALSO put to the
+// reference's own boxes (aabb.h:41-66, from the triangle's bvh_node up to the root), and what the shortcuts above would
+// have answered is compared with it.  The answer used is the reference's, so images do not change.
+//  [0] far-end ties seen            [1] settled by the face bits alone      [2] settled by the exact-plane distance
+//  [3] left to the boxes            [4] wrong among [1]                     [5] wrong among [2]
+//  [6] accepted hits away from both ends of the interval and from the outline (taken as reached without a test)
+//  [7] of those, not reached by the reference
+__device__ unsigned long long g_tie_counts[8];
+BDPT_DEV void tie_check_record(bool tie, const GpuTri& tr, V3 o, V3 d, double max_t, bool reached) {
+    if (!tie) {
+        atomicAdd(&g_tie_counts[6], 1ull);
+        if (!reached) atomicAdd(&g_tie_counts[7], 1ull);
+        return;
+    }
+    atomicAdd(&g_tie_counts[0], 1ull);
+    const int by_bits = far_end_tie<false>(tr, o, d, max_t), by_plane = far_end_tie<true>(tr, o, d, max_t);
+    if (by_bits == 0) {
+        atomicAdd(&g_tie_counts[1], 1ull);
+        if (!reached) atomicAdd(&g_tie_counts[4], 1ull);
+    } else if (by_plane != 2) {
+        atomicAdd(&g_tie_counts[2], 1ull);
+        if ((by_plane == 0) != reached) atomicAdd(&g_tie_counts[5], 1ull);
+    } else {
+        atomicAdd(&g_tie_counts[3], 1ull);
+    }
+}
+#endif
+
 constexpr int kQuadStackDepth = kQuadStackEntries;
 constexpr int32_t kPop = (int32_t)0x80000000;   // neither an interior index (>= 0) nor a leaf reference
 
@@ -646,6 +675,13 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                         // grazing one counts only if the reference's own boxes let it through.
                         // (to, td: the ray as the triangle's own boxes see it)
                         int ask = grazes(tr, u, v, t, det, gbits) ? 2 : (nearly_equal(t, closest) ? far_end_tie<true>(tr, to, td, closest) : 0);
+#ifdef BDPT_TIE_CHECK
+                        if (!grazes(tr, u, v, t, det, gbits)) {
+                            const bool reached = ref.reaches(sc, INSTANCED ? (uint32_t)tr.pad : sc.sleaf[tr.pad], o, d, closest);
+                            tie_check_record(nearly_equal(t, closest), tr, to, td, closest, reached);
+                            ask = reached ? 0 : 1;
+                        }
+#endif
                         if (ask == 2) ask = ref.reaches(sc, INSTANCED ? (uint32_t)tr.pad : sc.sleaf[tr.pad], o, d, closest) ? 0 : 1;
                         if (ask == 0) { h.tri = tr.pad; done = true; leaf_left = 0; }
                     }
@@ -1449,6 +1485,13 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
                     double t, u, v, det;
                     if (tri_candidate(own, g.origin, g.dir_unit, 0.001, t, u, v, det) && t <= g.max_t) {
                         int ask = grazes(own, u, v, t, det, gbits) ? 2 : (nearly_equal(t, g.max_t) ? far_end_tie<true>(own, g.origin, g.dir_unit, g.max_t) : 0);
+#ifdef BDPT_TIE_CHECK
+                        if (!grazes(own, u, v, t, det, gbits)) {
+                            const bool reached = reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t);
+                            tie_check_record(nearly_equal(t, g.max_t), own, g.origin, g.dir_unit, g.max_t, reached);
+                            ask = reached ? 0 : 1;
+                        }
+#endif
                         if (ask == 2) ask = reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t) ? 0 : 1;
                         if (ask == 0) emit = false;
                     }
@@ -1779,6 +1822,20 @@ __global__ __launch_bounds__(kBlock) void k_visible_out(WfBuffers wb, uint32_t n
 }  // namespace
 
 // ------------------------------------------------------------------------------ launchers
+hipError_t wf_tie_counts(unsigned long long* out8, bool reset) {
+#ifdef BDPT_TIE_CHECK
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tie_counts), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_tie_counts), zero, sizeof(zero));
+    }
+    return e;
+#else
+    (void)out8; (void)reset;
+    return hipErrorNotSupported;
+#endif
+}
+
 int64_t wf_owned_rows_before(int64_t y, int shard_rows, int shard_count, int shard_index) {
     const int64_t cycle = (int64_t)shard_rows * shard_count;
     int64_t part = y % cycle - (int64_t)shard_index * shard_rows;

@@ -365,6 +365,18 @@ int bdpt_device_random_doubles(bdpt_context* ctx, uint64_t seed, uint64_t pixel,
  * 8 log(a) as the device evaluates the std::log of src/materials/volumes/constant_medium.h:40 */
 int bdpt_device_arith(bdpt_context* ctx, int op, const double* a, const double* b, uint64_t n, double* out);
 
+/* Test hook of the cross-check build (libbdpt_amd_tiecheck.so, `make tiecheck`): visibility rays whose far end lies ON a
+ * surface tie with the end of their interval (src/camera.h:432-437), and whether the reference gets to test that surface's
+ * triangle is decided by its own boxes (src/acceleration/aabb.h:41-66).  The library settles most of those ties in place;
+ * the cross-check build also walks the reference's boxes for every one of them (and for every other accepted hit of a
+ * visibility ray away from the triangle's outline), answers with the walk's result and counts:
+ *   out[0] far-end ties seen, out[1] settled by the face bits alone, out[2] settled by the exact-plane distance,
+ *   out[3] left to the boxes anyway, out[4] / out[5] wrong answers among [1] / [2],
+ *   out[6] other accepted hits (taken as reached without a test), out[7] of those, not reached by the reference.
+ * Counters cover every render and query since the last reset (process-wide per GPU).  BDPT_ERR_UNSUPPORTED in the normal
+ * build.  Waits for the device. */
+int bdpt_debug_tie_counts(bdpt_context* ctx, uint64_t* out8, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -522,25 +522,38 @@ def unidirectional_fixtures(tmp):
 
 def glibc_tolerance_fixture(tmp):
     """The UNMODIFIED-libm reference (glibc's own sin / cos / pow, ref_harness_glibc) at a converged sample count:
-    crops at 1024 samples per pixel.  What the stated tolerance - per-pixel L2 of the mean radiance below 1e-3 - is
-    measured against (the other fixtures use correctly rounded sin / cos / pow5, which the HIP kernels reproduce bit
-    for bit; glibc's last-bit differences flip a few visibility ties per thousand samples)."""
+    crops at the full sample count of the configuration.  What the stated tolerance - per-pixel L2 of the mean radiance
+    below 1e-3 - is measured against (the other fixtures use correctly rounded sin / cos / pow5, which the HIP kernels
+    reproduce bit for bit; glibc's last-bit differences flip a few visibility ties per thousand samples).
+    `glass`, `coffee` and `coffee_diffuse` are crops of the two scenes the tolerance is stated for: scenes/glass-of-water.yaml at
+    1920x1080, 1024 spp, depth 12 and scenes/coffee_machine.yaml at 1920x1080, 512 spp (484 used), depth 10, both with
+    the stand-in meshes."""
     out = {}
     for name, scene, rect, seed in (("cornell", scenes.cornell_box(48, 1024, 10), (16, 16, 32, 32), 3),
-                                    ("mixed3k", scenes.mixed_materials_3k(40, 1024, 8), (14, 14, 26, 26), 5)):
+                                    ("mixed3k", scenes.mixed_materials_3k(40, 1024, 8), (14, 14, 26, 26), 5),
+                                    ("glass", scenes.glass_of_water_standin(1920, 1080, 1024, 12), (944, 520, 976, 536), 0),
+                                    ("coffee", scenes.coffee_machine_standin(1920, 1080, 512, 10), (900, 560, 932, 576), 0),
+                                    # (the crop above shows the glass cups; this one the lambertian wall beside the machine)
+                                    ("coffee_diffuse", scenes.coffee_machine_standin(1920, 1080, 512, 10), (600, 600, 632, 616), 0)):
         spath = os.path.join(tmp, "tol_" + name + ".scene")
         blob = scene.to_bytes()
         with open(spath, "wb") as f:
             f.write(blob)
         x0, y0, x1, y1 = rect
-        run(HARNESS_GLIBC, spath, "render", seed, x0, y0, x1, y1, os.path.join(tmp, "tol.fb"))
-        run(HARNESS, spath, "render", seed, x0, y0, x1, y1, os.path.join(tmp, "tol_cr.fb"))
+        spp_used = int(np.sqrt(scene.camera.samples_per_pixel)) ** 2
+        # (the two harness runs side by side: each is single-threaded)
+        jobs = [subprocess.Popen([b, spath, "render", str(seed), str(x0), str(y0), str(x1), str(y1), os.path.join(tmp, o)])
+                for b, o in ((HARNESS_GLIBC, "tol.fb"), (HARNESS, "tol_cr.fb"))]
+        for j in jobs:
+            if j.wait() != 0:
+                sys.exit("harness failed on " + name)
         out[name + "_scene_sha256"] = np.frombuffer(hashlib.sha256(blob).digest(), dtype=np.uint8)
         out[name + "_rect"] = np.array(rect, dtype=np.int32)
         out[name + "_seed"] = np.array([seed], dtype=np.uint64)
+        out[name + "_spp_used"] = np.array([spp_used], dtype=np.int32)
         out[name + "_framebuffer_glibc"] = rd(os.path.join(tmp, "tol.fb")).reshape(y1 - y0, x1 - x0, 3)
         out[name + "_framebuffer"] = rd(os.path.join(tmp, "tol_cr.fb")).reshape(y1 - y0, x1 - x0, 3)
-        d = (out[name + "_framebuffer_glibc"] - out[name + "_framebuffer"]) / 1024.0
+        d = (out[name + "_framebuffer_glibc"] - out[name + "_framebuffer"]) / float(spp_used)
         print("glibc_tolerance", name, "max per-pixel L2 of the mean radiance: %.3e, pixels that differ: %d of %d" % (
             np.sqrt((d ** 2).sum(axis=2)).max(), (d != 0).any(axis=2).sum(), d.shape[0] * d.shape[1]))
     np.savez_compressed(os.path.join(OUT, "glibc_tolerance.npz"), **out)
@@ -562,6 +575,30 @@ def new_fixtures(tmp):
     glibc_tolerance_fixture(tmp)
 
 
+def write_provenance():
+    """Compiler, flags and C library behind the fixtures; rewritten by every mode of this script (a fixture made
+    piecewise with --only-... comes from the same harness binaries as the rest)."""
+    flags = ""
+    with open(os.path.join(ROOT, "oracle", "Makefile")) as f:
+        for line in f:
+            if line.startswith("PINFLAGS"):
+                flags = "-std=c++17 " + line.split("=", 1)[1].strip()
+    prov = {
+        "generator": "tests/golden/make_golden.py",
+        "reference": "teehee567/Bidirectional-Path-Tracer @ 2025-11-21 (headers compiled in place from /root/reference/src)",
+        "compiler": subprocess.run(["g++", "--version"], capture_output=True, text=True).stdout.splitlines()[0],
+        "flags": flags,
+        "harness_sha256": {os.path.basename(b): hashlib.sha256(open(b, "rb").read()).hexdigest() for b in (HARNESS, HARNESS_GLIBC, HARNESS_NOSHIM)},
+        "libc": subprocess.run(["ldd", "--version"], capture_output=True, text=True).stdout.splitlines()[0],
+        "libm": "ref_harness: sin / cos / pow(., 5) / log interposed by oracle/ref_harness/cr_libm.c (correctly rounded double-double "
+                "evaluation; -fno-builtin-... keeps every call a real call); ref_harness_glibc: the same source with glibc's own libm "
+                "(`framebuffer_glibc_libm` in cornell24.npz, `*_framebuffer_glibc` in glibc_tolerance.npz)",
+        "rng": "per-(pixel,sample) counter streams, oracle/oracle_rng.h; serial_mt.npz uses the reference's own src/main.h",
+    }
+    with open(os.path.join(OUT, "PROVENANCE.json"), "w") as f:
+        json.dump(prov, f, indent=2)
+
+
 def main():
     for b in (HARNESS, HARNESS_GLIBC, HARNESS_NOSHIM):
         if not os.path.exists(b):
@@ -569,22 +606,27 @@ def main():
     if "--only-defocus" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
             golden_for("showcase_defocus", scenes.showcase_with_defocus(32, 16, 6), tmp, seed=13, sample_crop=(8, 8, 24, 24))
+        write_provenance()
         return
     if "--only-composite" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
             composite_fixtures(tmp)
+        write_provenance()
         return
     if "--only-tolerance" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
             glibc_tolerance_fixture(tmp)
+        write_provenance()
         return
     if "--only-new" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
             new_fixtures(tmp)
+        write_provenance()
         return
     if "--only-unidirectional" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
             unidirectional_fixtures(tmp)
+        write_provenance()
         return
     with tempfile.TemporaryDirectory() as tmp:
         unidirectional_fixtures(tmp)
@@ -628,18 +670,7 @@ def main():
                             scene_sha256=np.frombuffer(hashlib.sha256(sc.to_bytes()).digest(), dtype=np.uint8))
         print("serial_mt ok")
 
-    prov = {
-        "generator": "tests/golden/make_golden.py",
-        "reference": "teehee567/Bidirectional-Path-Tracer @ 2025-11-21 (headers compiled in place from /root/reference/src)",
-        "compiler": subprocess.run(["g++", "--version"], capture_output=True, text=True).stdout.splitlines()[0],
-        "flags": "-std=c++17 -O2 -ffp-contract=off -fno-builtin-sin -fno-builtin-cos -fno-builtin-pow -fno-builtin-log -pthread",
-        "libc": subprocess.run(["ldd", "--version"], capture_output=True, text=True).stdout.splitlines()[0],
-        "libm": "sin/cos/pow(.,5)/log interposed by oracle/ref_harness/cr_libm.c (correctly rounded); "
-                "`framebuffer_glibc_libm` in cornell24.npz is the same render with glibc's own libm",
-        "rng": "per-(pixel,sample) counter streams, oracle/oracle_rng.h; serial_mt.npz uses the reference's own src/main.h",
-    }
-    with open(os.path.join(OUT, "PROVENANCE.json"), "w") as f:
-        json.dump(prov, f, indent=2)
+    write_provenance()
 
 
 if __name__ == "__main__":
