@@ -27,9 +27,11 @@ Rank 0 prints ONE JSON line; at N = 1 it also carries
   "cpu_baseline" : the reference's own headers (compiled in place into oracle/_ref, kind "reference") timed on the
                    host cores over a bounded pixel lattice of the same workload, with the CPU oracle (restatement of
                    the reference path, FP64, same streams; kind "port") beside it under "port".
-  "extra"        : connection-heavy workloads, 3 frames each: the Cornell box at 512 x 512 x 256 spp and a
-                   10.2 M-triangle lattice at 4096 x 4096 x 64 spp, each with a parity check of pixels against the
-                   CPU oracle.
+  "extra"        : connection-heavy workloads, 2-3 frames each: the Cornell box at 512 x 512 x 256 spp, the coffee machine at
+                   1920 x 1080 x 484 spp and a 10.2 M-triangle lattice at 4096 x 4096 x 64 spp (flattened and as instances),
+                   each with a parity check of 16 pixels against the CPU oracle at the full sample count.
+  "value_default_workspace" : the headline frames with the library's default workspace limit instead of 176 GB.
+For N > 1 the line carries "per_rank": each rank's render time and the duration of its all-reduce.
 """
 import argparse
 import csv
@@ -221,13 +223,38 @@ def run_cpu_baseline(seed, seconds, flat):
 
 
 # ------------------------------------------------------------------------------------------ rocprofv3 counter passes
-PMC_PASSES = [("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("l2", ["TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"])]
+PMC_PASSES = [("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("l2", ["TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"]),
+              # what the waves of a kernel do with their cycles (8 SQ counters = one pass; GRBM is a block of its own)
+              ("issue", ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
+                         "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"])]
+N_SIMD = 256 * 4             # compute units x SIMDs
+N_XCD = 8
+
+
+def issue_summary(k):
+    """Where the cycles of a kernel's waves go, from the SQ counters of the `issue` pass (all in the same unit, so the
+    ratios need no conversion): parked on memory / a barrier, waiting to issue, executing; the share of the 64 lanes a
+    VALU instruction has active (the gfx9 VALUUtilization formula); and - against the GPU-busy cycles of the same
+    dispatches, which rocprofv3 reports summed over the 8 XCDs - average resident waves and VALU-busy share per SIMD
+    (the gfx9 VALUBusy formula: SQ_ACTIVE_INST_VALU x 4 / SIMDs / busy cycles)."""
+    wc = k.get("SQ_WAVE_CYCLES", 0.0)
+    if not wc:
+        return None
+    gui = k.get("GRBM_GUI_ACTIVE", 0.0) / N_XCD
+    out = {"mem_wait_frac": k.get("SQ_WAIT_ANY", 0.0) / wc, "issue_wait_frac": k.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+           "executing_frac": k.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
+           "lanes_active": (k["SQ_THREAD_CYCLES_VALU"] / (k["SQ_ACTIVE_INST_VALU"] * 64.0)) if k.get("SQ_ACTIVE_INST_VALU") else None,
+           "valu_instructions_per_wave": (k.get("SQ_INSTS_VALU", 0.0) / k["SQ_WAVES"]) if k.get("SQ_WAVES") else None}
+    if gui:
+        out["waves_per_simd"] = wc * 4.0 / N_SIMD / gui
+        out["valu_busy_frac"] = k.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / N_SIMD / gui
+    return out
 
 
 def kernel_class(name):
     if "k_traverse" in name:
         return "k_traverse"
-    for k in ("k_shade", "k_gen_eye", "k_gen_light", "k_conn_gen", "k_conn_accum", "k_conn_prepare", "k_resolve", "render_kernel"):
+    for k in ("k_shade", "k_gen_eye", "k_gen_light", "k_conn_gen", "k_conn_accum", "k_conn_prepare", "k_resolve", "k_redo", "render_kernel"):
         if k in name:
             return k
     return "other"
@@ -279,6 +306,7 @@ def run_pmc_passes(workload, seed, timeout_s):
         k["hbm_bytes"] = k["hbm_read_bytes"] + k["hbm_write_bytes"]
         # one request of the vector L1 to the L2 moves one 128-byte line (reads) / 64 bytes (writes)
         k["l2_request_bytes"] = 128.0 * k.get("TCP_TCC_READ_REQ_sum", 0.0) + 64.0 * k.get("TCP_TCC_WRITE_REQ_sum", 0.0)
+        k["issue"] = issue_summary(k)
     return out
 
 
@@ -330,18 +358,20 @@ def spawn_ranks(args):
 
 
 # ------------------------------------------------------------------------------------------ timing
-def time_frames(scene, cam, fb, steps, warmup, seed, stream, rank=0, world=1, shard_rows=4, dist=None, megakernel=False):
-    """(elapsed seconds of `steps` frames, device ms of each timed frame).  Barrier + synchronize on both sides."""
+def time_frames(scene, cam, fb, steps, warmup, seed, stream, rank=0, world=1, shard_rows=4, dist=None, megakernel=False, reduce_ms=None):
+    """(elapsed seconds of `steps` frames, device ms of each timed frame).  Barrier + synchronize on both sides.
+    reduce_ms: a list that receives the duration of every timed frame's all-reduce on this rank (world > 1)."""
     import torch
     distributed = importlib.import_module(PKG + ".distributed")
     kernel_ms = []
+    reduce_events = [] if (world > 1 and reduce_ms is not None) else None
 
     def step(timed):
         def render_shard(buf, shard):
             scene.render_device(cam, buf.data_ptr(), seed=seed, shard=shard, stream=stream, time_kernel=timed, megakernel=megakernel)
             if timed:
                 kernel_ms.append(scene.last_kernel_ms())   # waits for the kernel's stop event
-        distributed.render_frame(render_shard, fb, rank, world, shard_rows, dist)
+        distributed.render_frame(render_shard, fb, rank, world, shard_rows, dist, reduce_events if timed else None)
 
     for _ in range(warmup):
         step(False)
@@ -356,7 +386,10 @@ def time_frames(scene, cam, fb, steps, warmup, seed, stream, rank=0, world=1, sh
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, kernel_ms
+    elapsed = time.perf_counter() - t0
+    if reduce_events:
+        reduce_ms.extend(a.elapsed_time(b) for a, b in reduce_events)
+    return elapsed, kernel_ms
 
 
 def oracle_parity(flat, cam, fb, seed, pixels):
@@ -414,6 +447,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic is then null)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (Cornell box, 10 M-triangle lattice)")
     ap.add_argument("--pmc-timeout", type=int, default=240)
+    ap.add_argument("--pmc-json", default="", help="also write the per-kernel counter sums of the counter passes to this file")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-pixels", default="", help=argparse.SUPPRESS)
@@ -452,6 +486,9 @@ def main():
                 pmc = run_pmc_passes(args.workload, args.seed, args.pmc_timeout)
             except Exception as e:      # never lose the bench line to the profiler
                 pmc = {"error": "counter passes raised %r" % (e,)}
+            if args.pmc_json:
+                with open(args.pmc_json, "w") as f:
+                    json.dump({"workload": args.workload, "passes": {t: c for t, c in PMC_PASSES}, **pmc}, f, indent=1)
 
     import torch
     import torch.distributed as dist
@@ -484,12 +521,26 @@ def main():
     fb = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
+    reduce_ms = []
     elapsed, kernel_ms = time_frames(scene, cam, fb, args.steps, args.warmup, args.seed, stream, rank, world, args.shard_rows, dist,
-                                     args.megakernel)
+                                     args.megakernel, reduce_ms)
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what each rank spent: its own share of the frame (device time of its render call) and the all-reduce, which
+        # includes the wait for the slowest rank
+        mine = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms)), sum(reduce_ms) / max(1, len(reduce_ms))], dtype=torch.float64,
+                            device="cuda" if backend == "nccl" else "cpu")
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        render = [float(g[0].item()) for g in gathered]
+        red = [float(g[1].item()) for g in gathered]
+        per_rank = {"render_ms": {"min": min(render), "max": max(render), "mean": sum(render) / world, "by_rank": render},
+                    "reduce_ms": {"min": min(red), "max": max(red), "by_rank": red,
+                                  "note": "all-reduce of the %d-byte framebuffer as timed on each rank; the shortest one is the collective itself, "
+                                          "the others include the wait for the slowest rank's render" % (W * H * 3 * 8)}}
 
     samples_per_step = W * H * spp_used * depth
     value = samples_per_step * args.steps / elapsed / 1e6
@@ -523,6 +574,8 @@ def main():
             "paths_per_s": W * H * spp_used * args.steps / elapsed,
         },
     }
+    if per_rank is not None:
+        out["per_rank"] = per_rank
 
     if rank == 0 and world == 1 and not args.no_roofline:
         # untimed counting pass over every 8th row band (same kernels with their work counters on)
@@ -586,22 +639,32 @@ def main():
                     "l2_frac_of_peak": l2_bytes / (avg_ms * 1e-3) / 1e9 / L2_PEAK_GBS,
                     "hbm_bytes_per_launch": traffic},
                 "limiter": "latency of dependent fetches (record -> four slab tests -> next record) with FP64 triangle tests in between: "
-                           "neither HBM nor L2 bandwidth is near its peak",
+                           "neither HBM nor L2 bandwidth is near its peak; `issue` says what the waves do with their cycles",
                 "summed_launch_ms_over_frame_ms": (ms0 + ms1) / ms,
                 "note": "launches of up to 4 batches in flight share the chip, so a launch's own duration is longer than its share of "
                         "the frame; the counter passes serialise the launches",
-                "pmc": {k: pmc[k] for k in ("command", "seconds", "error") if k in pmc} if pmc else None,
+                "issue": (kt or {}).get("issue"),
+                "pmc": {k: pmc[k] for k in ("command", "seconds", "error", "kernels") if k in pmc} if pmc else None,
                 "per_sample": per_sample,
                 "frame": frame,
             }
     if cpu is not None:
         out["cpu_baseline"] = cpu
 
+    if rank == 0 and world == 1 and not args.no_extras and not args.megakernel and "BDPT_BENCH_WORKSPACE_GB" not in os.environ:
+        # the same frames with the library's own default workspace limit (32 GiB) instead of the 176 GB this program asks for
+        ctx.set_workspace_limit(0)
+        dflt_elapsed, _ = time_frames(scene, cam, fb, args.steps, 1, args.seed, stream)
+        out["value_default_workspace"] = samples_per_step * args.steps / dflt_elapsed / 1e6
+        out["config"]["workspace"] = {"value": "bdpt_context_set_workspace_limit(176 GB): batches of up to 2^26 samples",
+                                      "value_default_workspace": "library default (32 GiB, at most a quarter of the free memory)"}
+        ctx.set_workspace_limit(int(os.environ.get("BDPT_BENCH_WORKSPACE_GB", "176")) << 30)
+
     if rank == 0 and world == 1 and not args.no_extras and not args.megakernel and args.workload == "glass-of-water-1080p":
         scene.close()
         scene = None
         extras = {}
-        for name, pixels in (("cornell-512", 8), ("sphere-lattice-10m-4096", 6), ("sphere-lattice-instanced-10m-4096", 4)):
+        for name, pixels in (("cornell-512", 16), ("coffee-machine-1080p", 16), ("sphere-lattice-10m-4096", 16), ("sphere-lattice-instanced-10m-4096", 16)):
             try:
                 extras[name] = extra_leg(ctx, name, args.seed, 3 if name == "cornell-512" else 2, stream, pixels)
             except Exception as e:      # the headline line must not depend on an extra

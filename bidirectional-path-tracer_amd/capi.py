@@ -456,14 +456,14 @@ class Scene:
                                            C.c_void_p(stream)))
 
     def render_device_static(self, cam_state: CameraState, d_framebuffer: int, seed=0, rect=None, shard=(0, 1, 1),
-                             want_stats=False, stream: int = 0, time_kernel=False):
+                             want_stats=False, stream: int = 0, time_kernel=False, unidirectional=False):
         """bdpt_render_device_static: the same render out of the library's static workspace, allocating nothing."""
         p = RenderParams()
         p.seed = seed
         if rect is not None:
             p.x0, p.y0, p.x1, p.y1 = [int(v) for v in rect]
         p.shard_index, p.shard_count, p.shard_rows = shard
-        p.flags = self._flags(want_stats, time_kernel)
+        p.flags = self._flags(want_stats, time_kernel, unidirectional=unidirectional)
         _check(self.lib.bdpt_render_device_static(self.ctx.h, self.h, C.byref(cam_state), C.byref(p), C.c_void_p(d_framebuffer),
                                                   C.c_void_p(stream)))
 

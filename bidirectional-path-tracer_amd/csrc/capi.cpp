@@ -66,7 +66,7 @@ struct Knobs {
     int chunk;
     int no_first_leaf;    // 1: shadow rays start at the root like all others
     int first_leaf_mb;    // largest triangle table (MB) whose shadow rays test their far end's triangle first
-    int redo_blocks;      // workgroups of k_redo; 0: eight per compute unit
+    int redo_blocks;      // workgroups of k_redo; 0: one per compute unit
 };
 
 Knobs read_knobs() {
@@ -284,8 +284,17 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     cfg.textured = scene->dev.tex != nullptr;
     cfg.ordered = scene->ordered;
     if (cfg.instanced) { cfg.lds_scene = false; cfg.lds_bytes = 0; }      // (the staged variants carry no instance code)
-    cfg.own_test = cfg.lds_scene;
     cfg.ref_tree_bytes = cfg.lds_scene ? (((size_t)scene->dev.n_nodes * (sizeof(GpuNode) + sizeof(uint32_t)) + 15) & ~(size_t)15) : 0;
+    // the visibility instantiation of a staged scene holds scene, stack and the reference's tree at once: all of it has to
+    // fit a compute unit's 160 KiB (it does up to ~520 triangles, which is where kSceneLdsLimit ends too)
+    if (cfg.lds_scene && cfg.lds_bytes + (size_t)(kn.lds_stack + 1) * kBlock * sizeof(double) + cfg.ref_tree_bytes + 1024 > ((size_t)160 << 10)) {
+        cfg.lds_scene = false; cfg.lds_bytes = 0; cfg.ref_tree_bytes = 0;
+    }
+    cfg.conn_lds_bytes = cfg.ref_tree_bytes + (size_t)scene->dev.n_tris * (sizeof(GpuTri) + 8);
+    // k_conn_gen tests the far end's own triangle from tables in LDS: those and its 15 KiB of static tables must fit a
+    // compute unit's 160 KiB (they do for every scene that fits kSceneLdsLimit; checked all the same)
+    cfg.own_test = cfg.lds_scene && cfg.conn_lds_bytes + ((size_t)16 << 10) <= ((size_t)160 << 10);
+    if (!cfg.own_test) cfg.conn_lds_bytes = 0;
     cfg.top_nodes = (uint32_t)kn.lds_kb * 1024u / 128u;
     cfg.lds_stack = kn.lds_stack;
     int per_cu = 1;
@@ -1180,8 +1189,14 @@ int bdpt_render_device_static(bdpt_context* ctx, const bdpt_scene* scene, const 
     if (ctx->static_ws_status != hipSuccess || !ctx->static_ws)
         return fail(BDPT_ERR_DEVICE, std::string("the static workspace of this GPU could not be located: ") + hipGetErrorString(ctx->static_ws_status));
     DeviceGuard guard(ctx->device);
-    return render_impl(ctx, scene, cam, params, static_cast<double*>(d_framebuffer), static_cast<hipStream_t>(stream),
-                       ctx->static_ws, kStaticScratchBytes);
+    // every context and stream of this GPU shares the one workspace: this call starts after the previous one has ended
+    HIP_TRY(static_scratch_begin(ctx->device, static_cast<hipStream_t>(stream)));
+    const int rc = render_impl(ctx, scene, cam, params, static_cast<double*>(d_framebuffer), static_cast<hipStream_t>(stream),
+                               ctx->static_ws, kStaticScratchBytes);
+    const hipError_t e = static_scratch_end(ctx->device, static_cast<hipStream_t>(stream));
+    if (rc != BDPT_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "static_scratch_end");
+    return BDPT_OK;
 }
 
 int bdpt_render_get_stats(bdpt_context* ctx, bdpt_stats* out) {

@@ -80,6 +80,7 @@ struct WfLaunchCfg {
     bool own_test;        // k_conn_gen tests the light vertex's own triangle (from tables in LDS) and keeps the pairs' contributions
     size_t lds_bytes;
     size_t ref_tree_bytes;    // LDS copy of the reference's tree (nodes + parents) for scenes staged in LDS
+    size_t conn_lds_bytes;    // dynamic LDS of k_conn_gen's own-triangle variant: that copy, then triangles, grazing thresholds, leaf nodes
     int refill_threshold;     // a wave fetches new rays when at least this many of its lanes are idle
     int leaf_threshold;       // lanes of a wave that must stand at a leaf before the wave turns to triangle tests
     int leaf_inner;           // ... and it stays with the triangles of those leaves while this many lanes have one left

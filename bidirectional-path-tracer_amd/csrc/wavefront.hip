@@ -153,9 +153,8 @@ __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb,
 //    condition matters: the far end point lies ON a surface at t = max_t, and a node box whose face
 //    coincides with that surface is entered at t = max_t too - rounding decides, and the reference never
 //    tests the triangle when the box loses.  So a triangle accepted at an end of the interval counts only if
-//    reference_reaches() confirms the reference's own boxes from its node up to the root, in the reference's
-//    arithmetic.  (Both kinds of query share one residual assumption: a box is not lost to rounding when the
-//    ray is inside it for less than ~1e-12 of its length around the hit point.)
+//    the reference's own boxes, from its node up to the root, let the ray through in the reference's arithmetic
+//    (reference_reaches(), or far_end_tie() where the answer follows from the host's face bits).
 //
 // Exact ties.  The statement above - "a different hierarchy returns the reference's answer" - rests on the
 // reference reaching every triangle that would accept, i.e. on the boxes of its own tree passing aabb::hit for that
@@ -165,9 +164,10 @@ __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb,
 // the interval, or two hits at the same distance (coplanar surfaces: the second one's boxes are tested against an
 // interval that ends exactly where they begin, and rounding decides whether the reference ever tests it).  Such
 // hits are recognised by cheap sufficient conditions (grazes(), and nearly_equal() distances of a hit and the
-// running closest distance).  A visibility ray then asks reference_reaches(); a closest-hit ray gives up
-// the walk and is marked kHitRedo: the kernel that reads the hit next (k_shade, k_hits_out) repeats the query with
-// the reference's own traversal (device_core.h: walk) for it.  About one ray in 10^5 takes that road.
+// running closest distance).  A visibility ray then asks reference_reaches(); a closest-hit ray finishes its walk,
+// is marked kHitRedo and put on a list, and k_redo - launched after every closest-hit traversal - repeats the query
+// with the reference's own traversal (device_core.h: walk) and writes the reference's answer in its place.  Between
+// 7 rays in 10^6 (curved geometry) and 2 in 10^3 (boxes resting on boxes) take that road.
 // Why the remaining hits are safe: the hit point p is inside the triangle by at least bary_margin in every
 // barycentric coordinate, hence inside the triangle's box - and every box above it - by bary_margin x the box's
 // extent on every axis where that extent is at least 1e-4; on an axis where the box is thinner the reference pads
@@ -304,10 +304,13 @@ struct TopLdsMem {
 //   |b - o|/|d| * 1.5 * 2^-23  (d to FP32 and the reciprocal)  +  |o|/|d| * 2^-23  (o to FP32 and the product)
 //   + |t| * 2^-24  (the fma)   <=   (|b| + |o|) / |d| * 0.75 * 2^-21
 // and slack = (bound + |o|) * 2^-20 * |inv| (bound = largest |coordinate| of any box) is 2.6 times that.
-// A direction component of zero would give infinities and NaNs here; a component below 1e-30 in magnitude is taken as
-// +-1e-30 (the planes of a slab that holds o then lie at -huge and +huge, those of any other slab both at a distance
-// no interval reaches; a box within the slack of o still passes).  Should 1/d, o/d or the slack leave the FP32 range
-// all the same, the axis is left out: inv = 0 and (c_min, c_max) = (-inf, +inf) put no bound on the interval.
+// A direction component of zero would give infinities and NaNs here; a component below 2^-60 of the largest one in
+// magnitude is taken as +-2^-60 of it: over the whole length a ray can have inside the scene it then moves along that axis
+// by less than 2^-60 of the scene's extent, far inside the slack, like the true ray (the planes of a slab that holds o lie
+// at -huge and +huge, those of any other slab both at a distance no interval reaches; a box within the slack of o still
+// passes).  A ray whose LARGEST component is below 1e-18 (or not a number) is not culled at all - inv = 0 and
+// (c_min, c_max) = (-inf, +inf) put no bound on the interval - and so is any axis on which 1/d, o/d or the slack leave
+// the FP32 range all the same.
 // (The reference's own test, aabb.h:41-66, misses the box when the origin is outside that slab and passes
 // otherwise; both treatments are supersets of it.)
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -318,17 +321,20 @@ struct RayF32 {
 BDPT_DEV RayF32 ray_f32(V3 o, V3 d, float bound) {
     RayF32 r;
     const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    const float largest = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf((float)d.x), __builtin_fabsf((float)d.y)), __builtin_fabsf((float)d.z));
+    const float least = largest * 0x1p-60f;
+    const bool sane = largest >= 1e-18f && (largest - largest == 0.0f);       // (false for a NaN or infinite component as well)
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         // (leaving the axis out instead sends a ray that runs inside an axis-parallel plane - two points of one floor
         // with exactly equal heights - through every box above and below it: 20 x the time for such query segments)
         const float d32 = (float)dd[a];
-        const float inv = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d32), 1e-30f), d32));
+        const float inv = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d32), least), d32));
         const float of = (float)oo[a];
         const float c = -(of * inv);
         const float slack = (bound + __builtin_fabsf(of)) * 0x1p-20f * __builtin_fabsf(inv) * 1.000001f;
         // (x - x == 0) is false exactly for infinities and NaNs
-        const bool usable = (inv - inv == 0.0f) && (c - c == 0.0f) && (slack - slack == 0.0f);
+        const bool usable = sane && (inv - inv == 0.0f) && (c - c == 0.0f) && (slack - slack == 0.0f);
         r.inv[a] = usable ? (f2){inv, inv} : (f2){0.0f, 0.0f};
         // 1/d > 0: the min plane is the near one (gets -slack); 1/d < 0: the max plane is
         r.c[a] = !usable ? (f2){-__builtin_inff(), __builtin_inff()}
@@ -1898,6 +1904,11 @@ static size_t traverse_lds_bytes(const WfLaunchCfg& cfg) {
 hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu) {
     const size_t shm = traverse_lds_bytes(cfg);
     hipError_t e;
+    if (cfg.own_test) {      // k_conn_gen's own-triangle variant stages the reference's tree as well: more than 64 KiB from ~250 triangles on
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conn_gen<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.conn_lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conn_gen<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.conn_lds_bytes);
+        if (e != hipSuccess) return e;
+    }
     if (cfg.instanced) {
         e = prepare_traverse<false, false, false, true>(shm, blocks_per_cu);
         if (e == hipSuccess) e = prepare_traverse<false, true, false, true>(shm, nullptr);
@@ -2055,7 +2066,7 @@ hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers
     dim3 grid(cfg.conn_blocks), block(kStageBlock);
     if (cfg.own_test) {
         // LDS: the reference's tree, then the triangles with their grazing thresholds and leaf nodes
-        const size_t shm = cfg.ref_tree_bytes + (size_t)sc.n_tris * (sizeof(GpuTri) + 8);
+        const size_t shm = cfg.conn_lds_bytes;
         if (stats) hipLaunchKernelGGL((k_conn_gen<true, true>), grid, block, shm, st, sc, cam, wb, a, conn_count, shadow_count, stats);
         else hipLaunchKernelGGL((k_conn_gen<false, true>), grid, block, shm, st, sc, cam, wb, a, conn_count, shadow_count, stats);
     } else if (cfg.textured) {

@@ -27,20 +27,34 @@ def owned_rows(height: int, shard: Tuple[int, int, int], y0: int = 0, y1: int = 
     return [j for j in range(max(0, y0), y1) if (j // rows) % count == idx]
 
 
-def render_frame(render_shard: Callable, fb, rank: int, world: int, shard_rows: int = 4, dist=None):
+def render_frame(render_shard: Callable, fb, rank: int, world: int, shard_rows: int = 4, dist=None, reduce_events=None):
     """One frame: `render_shard(fb, shard)` must fill the pixels `shard` owns in the torch tensor `fb`
     (H x W x 3, float64) and leave the others alone.  With world > 1, `fb` is zeroed first and summed
-    over ranks afterwards with `dist.all_reduce`."""
+    over ranks afterwards with `dist.all_reduce`.  `reduce_events`: a list that receives one (start, end) pair of
+    torch.cuda.Event around the all-reduce (its duration includes the wait for the slowest rank's render)."""
     shard = shard_of(rank, world, shard_rows)
     if world > 1:
         fb.zero_()
     render_shard(fb, shard)
     if world > 1:
-        if getattr(fb, "is_cuda", False) and dist.get_backend() == "gloo":
-            # rehearsal on a machine without RCCL peers: gloo reduces a host copy
-            host = fb.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            fb.copy_(host)
-        else:
-            dist.all_reduce(fb, op=dist.ReduceOp.SUM)
+        if reduce_events is not None and getattr(fb, "is_cuda", False):
+            import torch
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            _all_reduce(fb, dist)
+            ev[1].record()
+            reduce_events.append(ev)
+            return fb
+        _all_reduce(fb, dist)
+    return fb
+
+
+def _all_reduce(fb, dist):
+    if getattr(fb, "is_cuda", False) and dist.get_backend() == "gloo":
+        # rehearsal on a machine without RCCL peers: gloo reduces a host copy
+        host = fb.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        fb.copy_(host)
+    else:
+        dist.all_reduce(fb, op=dist.ReduceOp.SUM)
     return fb

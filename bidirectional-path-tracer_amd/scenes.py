@@ -602,6 +602,19 @@ def mixed_materials_3k(image_width: int = 40, samples_per_pixel: int = 16, max_d
     return s
 
 
+def cornell_spheres_480(image_width: int = 40, samples_per_pixel: int = 16, max_depth: int = 8) -> FlatScene:
+    """Cornell room (both boxes) with two coarse lambertian spheres: 484 triangles - the upper end of what the traversal
+    kernels stage completely in LDS (hierarchy + triangles within 64 KiB), where the copy of the reference's tree beside
+    them takes the dynamic LDS of the visibility and connection kernels well past 64 KiB."""
+    s = cornell_box(image_width, samples_per_pixel, max_depth, short_box=True)
+    blue = s.add_material(Material(LAMBERTIAN, (.2, .3, .7)))
+    sand = s.add_material(Material(LAMBERTIAN, (.7, .6, .3)))
+    add_uv_sphere(s, (140.0, 245.0, 150.0), 75.0, blue, 8, 16)
+    add_uv_sphere(s, (400.0, 300.0, 330.0), 70.0, sand, 8, 16)
+    s.camera.file_name = "cornell_spheres.png"
+    return s
+
+
 def coplanar_stack(image_width: int = 32, samples_per_pixel: int = 16, max_depth: int = 6) -> FlatScene:
     """Axis-aligned geometry chosen to land on the ties of the reference's traversal: a floor, a second quad lying
     exactly in the floor's plane (same t for both), a third partly overlapping both, an unrotated box standing

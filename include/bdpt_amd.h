@@ -286,16 +286,19 @@ int bdpt_render(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
  * allocation, which waits for earlier work.  One context renders one frame at a time. */
 int bdpt_render_device(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam,
                        const bdpt_render_params* params, void* d_framebuffer, void* stream);
-/* bdpt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc): same arguments, same framebuffer bit for bit, but the call allocates nothing - the table
- * of owned rows and the per-sample path state live in a workspace of 256 MiB that is part of the library's code
- * object (every GPU the library runs on holds its copy until the process ends), and the pipeline cuts the frame
- * into batches that fit it.  No counterpart in the reference.  Limits: the samples of ONE pixel must fit the
+/* bdpt_render_device for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, code that
+ * runs between the capture calls of others): same arguments, same framebuffer bit for bit, but the call allocates
+ * nothing - the table of owned rows and the per-sample path state live in a workspace of 256 MiB that is part of the
+ * library's code object (every GPU the library runs on holds its copy until the process ends), and the pipeline cuts
+ * the frame into batches that fit it.  No counterpart in the reference.  Limits: the samples of ONE pixel must fit the
  * workspace - about samples x (152 + 240 x max_depth) bytes, e.g. 1024 samples at depth 12 need 3 MB, fine; 65536
  * samples at depth 40 do not - otherwise BDPT_ERR_UNSUPPORTED; flags other than BDPT_RENDER_COUNT_WORK,
- * BDPT_RENDER_TIME_KERNEL and BDPT_RENDER_UNIDIRECTIONAL are refused (they need buffers of their own).  All calls on one GPU share that GPU's
- * workspace, whatever the context: calls that overlap on one GPU race, so issue them on one stream or order them
- * with events.  Smaller batches than bdpt_render_device's make it the slower of the two on large frames. */
+ * BDPT_RENDER_TIME_KERNEL and BDPT_RENDER_UNIDIRECTIONAL are refused (they need buffers of their own).  All calls on one
+ * GPU share that GPU's workspace, whatever the context or stream: the library orders them itself - a call's work starts
+ * after the previous call's has ended (one event per GPU, made when the first context is) - so they never overlap, and
+ * never race, on the device.  The call forks onto the library's internal streams and sets kernel attributes: it is
+ * not meant to be recorded into a HIP graph itself.  Smaller batches than bdpt_render_device's make it the slower of
+ * the two on large frames. */
 int bdpt_render_device_static(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_state* cam,
                               const bdpt_render_params* params, void* d_framebuffer, void* stream);
 /* Counters of the last bdpt_render_device call that requested them (synchronises). */

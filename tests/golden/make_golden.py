@@ -559,6 +559,73 @@ def glibc_tolerance_fixture(tmp):
     np.savez_compressed(os.path.join(OUT, "glibc_tolerance.npz"), **out)
 
 
+def extreme_queries_fixture(tmp):
+    """Queries at the edges of the number range and of the tie rules, answered by the reference harness:
+    * rays whose direction is tiny (all components ~1e-33: legal for bvh_node::hit with an infinite interval), huge
+      (~1e30), or has components 20 to 60 binades apart - the packed-FP32 box test of the traversal kernels must stay a
+      superset of aabb::hit (src/acceleration/aabb.h:41-66) for all of them;
+    * pairs that END on exactly flat, axis-aligned triangles lying in faces of the boxes above them - floor quads in one
+      plane, the faces of a box standing on the floor, a slab 1e-5 thick (its ancestors' boxes are padded by less than
+      1e-4) - approached from both sides and from points of the same plane: the far-end ties of camera::visible
+      (src/camera.h:425-438) that the kernels settle from host-made face bits."""
+    out = {}
+    for name, scene, seed in (("cornell24", scenes.cornell_box(48, 16, 10), 41), ("mixed3k", scenes.mixed_materials_3k(40, 16, 8), 42),
+                              ("coplanar", scenes.coplanar_stack(32, 16, 6), 43)):
+        rng = np.random.default_rng(seed)
+        spath = os.path.join(tmp, "xq_" + name + ".scene")
+        blob = scene.to_bytes()
+        with open(spath, "wb") as f:
+            f.write(blob)
+        o = lambda s: os.path.join(tmp, "xq_" + name + "." + s)
+        lo, hi = scene_box(scene)
+        ext = hi - lo
+        n = 1536
+        org = lo + rng.uniform(0.02, 0.98, (n, 3)) * ext
+        d = lo + rng.uniform(0.0, 1.0, (n, 3)) * ext - org
+        d /= np.linalg.norm(d, axis=1)[:, None]
+        kind = np.arange(n) % 6
+        scale = np.where(kind == 0, 1e-33, np.where(kind == 1, 1e30, np.where(kind == 2, 3e-21, 1.0)))
+        d = d * scale[:, None]
+        # components far apart: one axis scaled down by 2^-20 ... 2^-70
+        for k in np.flatnonzero(kind >= 3):
+            d[k, rng.integers(0, 3)] *= 2.0 ** -float(rng.integers(20, 71))
+            if kind[k] == 5:
+                d[k, rng.integers(0, 3)] *= 2.0 ** -float(rng.integers(20, 71))
+        rays = np.concatenate([org, d, np.full((n, 1), 0.001), np.full((n, 1), np.inf)], axis=1)
+        rays.tofile(o("rays"))
+        run(HARNESS, spath, "hits", o("rays"), o("hits"))
+        hits = rd(o("hits")).reshape(-1, 11)
+        # far ends on flat axis-aligned triangles
+        verts = scene.vertex_array().reshape(-1, 3, 3)
+        flat_tris = [t for t in range(len(verts)) if any(verts[t][0][a] == verts[t][1][a] == verts[t][2][a] for a in range(3))]
+        surf = hits[hits[:, 0] >= 0][:, 5:8]
+        pairs = []
+        for k in range(3072):
+            t = verts[flat_tris[rng.integers(0, len(flat_tris))]]
+            a, b = rng.uniform(0, 1, 2)
+            if a + b > 1:
+                a, b = 1 - a, 1 - b
+            if k % 8 == 0:              # few mantissa bits: points exactly representable on edges / inside
+                a, b = rng.integers(0, 5) / 8.0, rng.integers(0, 4) / 8.0
+            p = t[0] + a * (t[1] - t[0]) + b * (t[2] - t[0])
+            if k % 3 == 2:              # partner in the same plane (another point of a flat triangle)
+                t2 = verts[flat_tris[rng.integers(0, len(flat_tris))]]
+                a2, b2 = rng.uniform(0, 0.5, 2)
+                q = t2[0] + a2 * (t2[1] - t2[0]) + b2 * (t2[2] - t2[0])
+            else:
+                q = surf[rng.integers(0, len(surf))]
+            pairs.append(np.concatenate([q, p]) if k % 2 == 0 else np.concatenate([p, q]))
+        pairs = np.array(pairs)
+        pairs.tofile(o("pairs"))
+        run(HARNESS, spath, "visible", o("pairs"), o("vis"))
+        out[name + "_scene_sha256"] = np.frombuffer(hashlib.sha256(blob).digest(), dtype=np.uint8)
+        out[name + "_rays"], out[name + "_hits"] = rays, hits
+        out[name + "_pairs"], out[name + "_visible"] = pairs, rd(o("vis")).astype(np.uint8)
+        print("extreme_queries", name, ": %d rays (%d hit), %d pairs (%d visible), %d flat axis-aligned triangles"
+              % (n, (hits[:, 0] >= 0).sum(), len(pairs), out[name + "_visible"].sum(), len(flat_tris)))
+    np.savez_compressed(os.path.join(OUT, "extreme_queries.npz"), **out)
+
+
 def new_fixtures(tmp):
     """Scenes whose tables do not fit the LDS copy (the traversal kernels read them from global memory), and geometry
     made of exact ties."""
@@ -618,6 +685,11 @@ def main():
             glibc_tolerance_fixture(tmp)
         write_provenance()
         return
+    if "--only-extreme" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            extreme_queries_fixture(tmp)
+        write_provenance()
+        return
     if "--only-new" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
             new_fixtures(tmp)
@@ -653,6 +725,7 @@ def main():
         golden_for("showcase_defocus", scenes.showcase_with_defocus(32, 16, 6), tmp, seed=13, sample_crop=(8, 8, 24, 24))
 
         new_fixtures(tmp)
+        extreme_queries_fixture(tmp)
         composite_fixtures(tmp)
 
         # the unshimmed reference (real src/main.h: one serial default-seeded mt19937)

@@ -123,3 +123,13 @@ def test_ten_million_triangles_4096_64spp_depth10(scenes, ctx, oracle):
     assert flat.n_triangles == 960 * 22 ** 3 + 4
     check_full_size(flat, ctx, oracle, lambda W, H: [(int((a + 0.5) * W / 3), int((b + 0.5) * H / 2)) for a in range(3) for b in range(2)],
                     (2040, 2040, 2056, 2044), shard_counts=(2,))
+
+
+def test_ten_million_triangles_as_instances_4096_64spp_depth10(scenes, ctx, oracle):
+    """Configuration 5 as worded ("instanced"): 10 648 translate wrappers (src/objects/hittable.h:46-74) over six shared
+    960-triangle sphere meshes - 10.2 M triangles once instanced - 4096 x 4096, 64 spp, depth 10, on the pipeline's
+    two-level tables: shards, the single-kernel walk over the reference's own trees on a crop, oracle pixels."""
+    flat = scenes.sphere_lattice_instanced(22, 4096, 64, 10)
+    assert len(flat.objects) == 22 ** 3 and sum(o.n_triangles for o in flat.objects) == 960 * 22 ** 3
+    check_full_size(flat, ctx, oracle, lambda W, H: [(int((a + 0.5) * W / 3), int((b + 0.5) * H / 2)) for a in range(3) for b in range(2)],
+                    (2040, 2040, 2056, 2044), shard_counts=(2,))

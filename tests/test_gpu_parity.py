@@ -346,6 +346,42 @@ def test_large_scene_uses_global_memory_path(scenes, ctx, oracle):
     sc.close()
 
 
+def test_largest_scene_staged_in_lds(scenes, ctx, oracle):
+    """484 triangles: hierarchy + triangles still fit the 64 KiB the traversal kernels stage completely, and the copy of
+    the reference's tree beside them (967 nodes) takes the dynamic LDS of the visibility traversal to ~140 KiB and of
+    the connection kernel's own-triangle test to ~110 KiB - both far past the 64 KiB a kernel gets without asking.
+    Frame (pipeline with and without work counters, single kernel), hit records and visibility against the oracle."""
+    flat = scenes.cornell_spheres_480(40, 16, 8)
+    assert 450 <= flat.n_triangles <= 520
+    sc = ctx.scene(flat)
+    osc = oracle.scene(flat)
+    cam = capi.camera_initialize(flat.camera)
+    ofb, ostats, _ = osc.render(cam.as_array(), 40, cam.sqrt_spp, 8, 23, (0, 0, 40, cam.image_height))
+    assert ofb.max() > 0
+    assert_bit_equal(sc.render(cam, seed=23), ofb, "484 triangles, pipeline")
+    fb, st = sc.render(cam, seed=23, want_stats="work")
+    assert_bit_equal(fb, ofb, "484 triangles, pipeline with work counters")
+    assert st.shadow_rays > 0 and st.connection_pairs > st.shadow_rays
+    assert_bit_equal(sc.render(cam, seed=23, megakernel=True), ofb, "484 triangles, single kernel")
+    # surface points of random rays, and visibility between them (far ends ON surfaces: the staged tree decides the ties)
+    rng = np.random.default_rng(5)
+    v = flat.vertex_array().reshape(-1, 3)
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    n = 8000
+    o = rng.uniform(lo, hi, (n, 3))
+    rays = np.concatenate([o, rng.uniform(lo, hi, (n, 3)) - o, np.full((n, 1), 0.001), np.full((n, 1), np.inf)], axis=1)
+    hits = sc.trace_closest(rays)
+    ohits, _ = osc.trace_closest(rays)
+    assert_bit_equal(hits, ohits, "484 triangles, hit records")
+    pts = ohits[ohits[:, 0] >= 0][:, 5:8]
+    pairs = np.concatenate([pts[rng.integers(0, len(pts), 6000)], pts[rng.integers(0, len(pts), 6000)]], axis=1)
+    vis = sc.visible(pairs)
+    ovis = osc.visible(pairs)
+    assert np.array_equal(np.asarray(vis).astype(bool), np.asarray(ovis).astype(bool))
+    assert 0 < np.asarray(ovis).astype(bool).sum() < len(pairs)
+    sc.close()
+
+
 @pytest.mark.parametrize("big", [False, True])
 def test_more_materials_than_the_connection_stage_keeps_in_lds(scenes, ctx, oracle, big):
     """The connection stage works out the BSDF values of up to 128 materials once per workgroup; a scene with more

@@ -84,3 +84,69 @@ def test_static_workspace_limits_are_reported(scenes):
     rc = ctx.lib.bdpt_render_device_static(ctx.h, sc2.h, C.byref(cam), C.byref(p), C.c_void_p(fb.data_ptr()), None)
     assert rc == -4 and b"BDPT_RENDER_COUNT_WORK" in ctx.lib.bdpt_last_error()
     sc.close(); sc2.close(); ctx.close()
+
+
+def test_static_workspace_call_allocates_no_device_memory(scenes):
+    """The property the entry point exists for: after one warm-up call (code objects, kernel attributes), the free device
+    memory is the same before and after a call - plain scene, composite scene, with work counters - while the same
+    renders through bdpt_render_device do take memory for their workspace."""
+    import torch
+    from conftest import composite_scene
+    ctx = capi.Context(0)
+    flat = scenes.mixed_materials_3k(64, 64, 8)
+    sc = ctx.scene(flat)
+    cam = capi.camera_initialize(flat.camera)
+    cflat, _ = composite_scene(scenes, "cx_textures")
+    csc = ctx.scene(cflat)
+    ccam = capi.camera_initialize(cflat.camera)
+    fb = torch.zeros((cam.image_height, cam.image_width, 3), dtype=torch.float64, device="cuda")
+    cfb = torch.zeros((ccam.image_height, ccam.image_width, 3), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    calls = [lambda: sc.render_device_static(cam, fb.data_ptr(), seed=1, stream=stream),
+             lambda: csc.render_device_static(ccam, cfb.data_ptr(), seed=1, stream=stream),
+             lambda: sc.render_device_static(cam, fb.data_ptr(), seed=1, stream=stream, want_stats="work"),
+             lambda: sc.render_device_static(cam, fb.data_ptr(), seed=1, stream=stream, unidirectional=True)]
+    for call in calls:              # warm-up
+        call()
+    torch.cuda.synchronize()
+    for k, call in enumerate(calls):
+        free0, _ = torch.cuda.mem_get_info()
+        call()
+        call()
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 == free0, "static call %d changed the free device memory by %d bytes" % (k, free0 - free1)
+    # the allocating entry point is what takes memory for the same frame
+    free0, _ = torch.cuda.mem_get_info()
+    sc.render_device(cam, fb.data_ptr(), seed=1, stream=stream)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 < free0
+    sc.close(); csc.close(); ctx.close()
+
+
+def test_static_workspace_calls_from_two_contexts_and_streams_are_ordered(scenes):
+    """Two contexts, each on a stream of its own, share the GPU's one workspace: the library orders the calls (each
+    starts after the previous one has ended), so calls issued back to back without any synchronisation by the caller
+    still return the bits of bdpt_render_device."""
+    import torch
+    ctx_a, ctx_b = capi.Context(0), capi.Context(0)
+    flat_a, flat_b = scenes.mixed_materials_3k(72, 64, 8), scenes.cornell_box(64, 64, 6)
+    sc_a, sc_b = ctx_a.scene(flat_a), ctx_b.scene(flat_b)
+    cam_a, cam_b = capi.camera_initialize(flat_a.camera), capi.camera_initialize(flat_b.camera)
+    want_a = torch.zeros((cam_a.image_height, cam_a.image_width, 3), dtype=torch.float64, device="cuda")
+    want_b = torch.zeros((cam_b.image_height, cam_b.image_width, 3), dtype=torch.float64, device="cuda")
+    sc_a.render_device(cam_a, want_a.data_ptr(), seed=2, stream=torch.cuda.current_stream().cuda_stream)
+    sc_b.render_device(cam_b, want_b.data_ptr(), seed=3, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+    got_a = [torch.zeros_like(want_a) for _ in range(3)]
+    got_b = [torch.zeros_like(want_b) for _ in range(3)]
+    for k in range(3):              # interleaved, nothing in between
+        sc_a.render_device_static(cam_a, got_a[k].data_ptr(), seed=2, stream=s_a.cuda_stream)
+        sc_b.render_device_static(cam_b, got_b[k].data_ptr(), seed=3, stream=s_b.cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert torch.equal(got_a[k].view(torch.int64), want_a.view(torch.int64)), "context A, call %d" % k
+        assert torch.equal(got_b[k].view(torch.int64), want_b.view(torch.int64)), "context B, call %d" % k
+    sc_a.close(); sc_b.close(); ctx_a.close(); ctx_b.close()
