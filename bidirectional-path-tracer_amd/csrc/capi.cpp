@@ -67,6 +67,8 @@ struct Knobs {
     int no_first_leaf;    // 1: shadow rays start at the root like all others
     int first_leaf_mb;    // largest triangle table (MB) whose shadow rays test their far end's triangle first
     int redo_blocks;      // workgroups of k_redo; 0: one per compute unit
+    int conn_cap_tenths;  // shadow-queue entries per sample slot, in tenths of max_depth (10: depth entries per slot)
+    int conn_budget;      // vertex records a wave of k_connect stages at a time; 0: 160 (128 with textures), at least 2 x depth
 };
 
 Knobs read_knobs() {
@@ -84,6 +86,8 @@ Knobs read_knobs() {
     k.no_first_leaf = env_int("BDPT_WF_NO_FIRST_LEAF", 0, 0, 1);
     k.first_leaf_mb = env_int("BDPT_WF_FIRST_LEAF_MB", 1 << 20, 0, 1 << 20);
     k.redo_blocks = env_int("BDPT_WF_REDO_BLOCKS", 0, 0, 1 << 16);
+    k.conn_cap_tenths = env_int("BDPT_WF_CONN_CAP", 10, 5, 80);
+    k.conn_budget = env_int("BDPT_WF_CONN_BUDGET", 0, 0, 2048);
     return k;
 }
 
@@ -275,7 +279,18 @@ int render_composite(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
 }
 
 // launch shape of the persistent traversal kernels and of the stage kernels for one scene
-int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCfg& cfg) {
+// dynamic LDS of k_connect for a scene at a depth: `waves` staging areas of `budget` vertex records, then the tables of its
+// own-triangle test
+size_t conn_lds_need(uint32_t waves, uint32_t budget, bool textured, size_t own_bytes) {
+    return (size_t)waves * budget * (textured ? 13u : 10u) * sizeof(double) + own_bytes;      // (words of a vertex record, device_core.h)
+}
+constexpr size_t kConnLdsMost = (size_t)150 << 10;        // of a compute unit's 160 KiB
+// true when the connection kernel can stage the 2 x depth vertex records of one sample
+bool pipeline_can_connect(const bdpt_scene* scene, int depth) {
+    return conn_lds_need(1, 2u * (uint32_t)(depth > 0 ? depth : 1), scene->dev.tex != nullptr, 0) <= kConnLdsMost;
+}
+
+int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCfg& cfg, int depth = 1) {
     const Knobs& kn = ctx->knobs;
     cfg.lds_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuQuadNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
     cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
@@ -290,11 +305,27 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     if (cfg.lds_scene && cfg.lds_bytes + (size_t)(kn.lds_stack + 1) * kBlock * sizeof(double) + cfg.ref_tree_bytes + 1024 > ((size_t)160 << 10)) {
         cfg.lds_scene = false; cfg.lds_bytes = 0; cfg.ref_tree_bytes = 0;
     }
-    cfg.conn_lds_bytes = cfg.ref_tree_bytes + (size_t)scene->dev.n_tris * (sizeof(GpuTri) + 8);
-    // k_conn_gen tests the far end's own triangle from tables in LDS: those and its 15 KiB of static tables must fit a
-    // compute unit's 160 KiB (they do for every scene that fits kSceneLdsLimit; checked all the same)
-    cfg.own_test = cfg.lds_scene && cfg.conn_lds_bytes + ((size_t)16 << 10) <= ((size_t)160 << 10);
-    if (!cfg.own_test) cfg.conn_lds_bytes = 0;
+    // k_connect tests the far end's own triangle from tables in LDS (the reference's tree, triangles, grazing thresholds,
+    // leaf nodes): for scenes where those are small beside the vertex records the kernel stages (up to ~70 triangles)
+    const size_t own_bytes = cfg.ref_tree_bytes + (size_t)scene->dev.n_tris * (sizeof(GpuTri) + 8);
+    cfg.own_test = cfg.lds_scene && own_bytes <= ((size_t)16 << 10);
+    {
+        const uint32_t d = (uint32_t)(depth > 0 ? depth : 1);
+        uint32_t budget = kn.conn_budget > 0 ? (uint32_t)kn.conn_budget : (cfg.textured ? 128u : 160u);
+        if (budget < 2u * d) budget = 2u * d;
+        uint32_t waves = 4;
+        while (waves > 1 && conn_lds_need(waves, budget, cfg.textured, cfg.own_test ? own_bytes : 0) > ((size_t)64 << 10)) waves /= 2;
+        if (cfg.own_test && conn_lds_need(waves, budget, cfg.textured, own_bytes) > kConnLdsMost) cfg.own_test = false;
+        cfg.conn_waves = waves;
+        cfg.conn_rec_budget = budget;
+        cfg.conn_lds_bytes = conn_lds_need(waves, budget, cfg.textured, cfg.own_test ? own_bytes : 0);
+        if (cfg.conn_lds_bytes > kConnLdsMost) return fail(BDPT_ERR_UNSUPPORTED, "max_depth too large for the connection kernel's staging area");
+        // a wave takes the shadow queue in pieces that hold the pairs of any one sample at least four times over, so that
+        // at most a quarter of a piece is lost when the entries of a sample would straddle two pieces
+        const uint32_t sample_pairs = ((d * d + 63u) / 64u) * 64u;
+        cfg.conn_chunk = 4u * sample_pairs < 256u ? 256u : 4u * sample_pairs;
+        cfg.conn_blocks = 1; cfg.conn_passes = 1; cfg.conn_pass_pairs = 0;      // (render_wavefront sizes these with the batch)
+    }
     cfg.top_nodes = (uint32_t)kn.lds_kb * 1024u / 128u;
     cfg.lds_stack = kn.lds_stack;
     int per_cu = 1;
@@ -342,25 +373,49 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const bool connections = !unidirectional && (scene->host.has_lambertian || stats_mode != 0);
     const size_t vslots = unidirectional ? (size_t)(depth > 0 ? depth : 1) : (connections ? 2 * (size_t)(depth > 0 ? depth : 1) : 0);
     // (a scene with media keeps no shadow queue: its pairs are traced one after the other, k_conn_ordered)
-    const uint32_t vis_words = (connections && !scene->ordered) ? (uint32_t)((depth > 0 ? depth : 1) + 63) / 64 : 0;
-    const size_t shadow_per_slot = (connections && !scene->ordered) ? (size_t)(depth > 0 ? depth : 1) : 0;
+    const bool conn_queue = connections && !scene->ordered;
     WfLaunchCfg cfg;
-    { int rc = make_launch_cfg(ctx, scene, cfg); if (rc != BDPT_OK) return rc; }
-    const size_t kept_per_slot = cfg.own_test ? shadow_per_slot : 0;      // contributions kept by k_conn_gen<., true>
+    { int rc = make_launch_cfg(ctx, scene, cfg, depth); if (rc != BDPT_OK) return rc; }
+    const uint64_t d1 = (uint64_t)(depth > 0 ? depth : 1);
     const size_t rec_doubles = cfg.textured ? 13 : 10;                     // words of a vertex record (device_core.h)
     if (!scene->ordered && !pipeline_can_walk(scene)) return fail(BDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     if (n_owned >= ((int64_t)1 << 31)) return fail(BDPT_ERR_UNSUPPORTED, "more than 2^31 pixels in one call");
-    // bytes of state per sample slot
-    // A shadow ray of a scene too large for LDS first tests the triangle its far end lies on (WfBuffers::shadow_first, a
-    // ninth, 32-bit word per ray): +17 % on the 51 k-triangle coffee machine, +9 % on a 0.96 M-triangle lattice, +15 % on
-    // 10.2 M triangles.  (BDPT_WF_FIRST_LEAF_MB limits it to triangle tables up to that size.)
-    const bool first_leaf = !cfg.lds_scene && !cfg.ordered && scene->dev.tri_xpos != nullptr &&
+    // A shadow ray of a scene whose connection kernel does not test the far end's triangle itself first tests that
+    // triangle in the traversal (WfBuffers::shadow_first, a 32-bit word per ray): +17 % on the 51 k-triangle coffee machine,
+    // +9 % on a 0.96 M-triangle lattice, +15 % on 10.2 M triangles.  (BDPT_WF_FIRST_LEAF_MB limits it to triangle tables up
+    // to that size.)
+    const bool first_leaf = conn_queue && !cfg.own_test && scene->dev.tri_xpos != nullptr &&
                             scene->host.xtris.size() * sizeof(GpuTri) <= ((size_t)ctx->knobs.first_leaf_mb << 20) && !ctx->knobs.no_first_leaf;
-    const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 6 + vslots * rec_doubles * sizeof(double) +
-                            vis_words * sizeof(unsigned long long) + (shadow_per_slot * 8 + kept_per_slot * 3) * sizeof(double) +
-                            (first_leaf ? shadow_per_slot * 4 : 0) +
-                            (connections ? 9 : 0);        // (the slack of the shadow queue, see conn_blocks below)
-    const size_t n_counters = 8 + 8 * (size_t)(depth > 0 ? depth : 1);      // (+ one k_redo list size per closest-hit traversal launch)
+    // bytes of one shadow-queue entry: ray (7 doubles), flag, then either the kept contribution or the pair's indices and
+    // the triangle its walk starts at
+    const size_t entry_bytes = !conn_queue ? 0 : 7 * sizeof(double) + 1 + (cfg.own_test ? 3 * sizeof(double) : 4 + (first_leaf ? 4 : 0));
+    // queue entries per sample slot: max_depth of them by default (a sample has up to depth x depth pairs: the passes
+    // of the connection stage take as many samples at a time as the queue holds for certain)
+    const double cap_per_slot = !conn_queue ? 0.0 : (double)d1 * kn.conn_cap_tenths / 10.0;
+    // bytes of state per sample slot
+    const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 5 + (scene->ordered ? 4 : 0) + vslots * rec_doubles * sizeof(double) +
+                            (conn_queue ? 8 + 1 : 0) +
+                            // the queue: a third more than what a pass may be given (pieces partly lost), a quarter more for
+                            // the pieces the waves leave unused at the end (conn_blocks below is limited accordingly)
+                            (size_t)(cap_per_slot * (4.0 / 3.0 + 0.25) * (double)entry_bytes + 1.0);
+    // Passes of the connection stage: the queue holds `cap` entries, of which the pieces the waves of k_connect leave partly
+    // unused at the end (`slack`) and up to a quarter of every piece may be lost; what remains is what a pass may be given
+    // (pass_pairs, at least two tiles' worth).  Every pass but the last is filled to within one tile, so this many passes
+    // take whatever the samples turn out to have (most of them are empty and return at once).
+    const uint64_t tile_worst = (uint64_t)kConnTile * d1 * d1;
+    auto conn_plan = [&](uint64_t slots, uint32_t blocks, uint64_t& cap, uint64_t& pass_pairs, uint32_t& passes) {
+        const uint64_t slack = (uint64_t)blocks * cfg.conn_waves * cfg.conn_chunk;
+        uint64_t useful = (uint64_t)((double)slots * cap_per_slot);
+        if (useful < 3 * tile_worst) useful = 3 * tile_worst;
+        cap = useful + useful / 3 + slack + 64;          // three quarters of (cap - slack) >= useful
+        pass_pairs = useful;
+        const uint64_t worst = slots * d1 * d1;
+        passes = (uint32_t)((worst + (useful - tile_worst) - 1) / (useful - tile_worst)) + 1u;
+    };
+    // (a large batch needs ~ depth x depth / cap_per_slot passes, a batch of a few hundred slots up to 1.5 x depth)
+    const size_t by_queue_size = conn_queue ? (size_t)((double)(d1 * d1) / cap_per_slot) : 0;
+    const size_t max_passes = conn_queue ? 2 * (by_queue_size > d1 ? by_queue_size : (size_t)d1) + 8 : 0;
+    const size_t n_counters = 8 + 6 * (size_t)d1 + 2 * max_passes;      // queue sizes and cursors of every launch, sizes of the k_redo lists
     // Wavefront state of all batches in flight.  Large batches mean few, long launches (a frame is tens of thousands
     // of them), so a host that wants the last tenth of throughput raises the limit (bdpt_context_set_workspace_limit).
     size_t budget;
@@ -381,9 +436,11 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         }
     }
     int want_streams = kn.streams;
-    // room for the 256-byte alignment of the 15 arrays of a workspace and for its counters
-    const size_t per_stream_overhead = 18 * 256 + align256(n_counters * 4) + (size_t)kConnSlackPerBlock * 9 * sizeof(double) +
-                                       (size_t)kVtxGroup * (vslots * rec_doubles + kept_per_slot * 3) * sizeof(double);     // (vertex arrays hold whole groups of slots)
+    // room for the 256-byte alignment of the arrays of a workspace, its counters, the unused pieces of the shadow queue, the
+    // least size of that queue, the tile sums and the vertex arrays' last group
+    const size_t per_stream_overhead = 24 * 256 + align256(n_counters * 4) + align256((max_passes + 1) * 4) +
+                                       (conn_queue ? ((size_t)cfg.conn_waves * cfg.conn_chunk + 4 * tile_worst + 64) * entry_bytes : 0) +
+                                       (size_t)kVtxGroup * vslots * rec_doubles * sizeof(double);
     if (budget / want_streams <= per_stream_overhead + per_slot * (size_t)spp) want_streams = 1;
     if (budget <= per_stream_overhead + per_slot * (size_t)spp)
         return fail(BDPT_ERR_UNSUPPORTED, fixed_ws ? "the samples of one pixel exceed the static workspace (samples per pixel x depth too large for bdpt_render_device_static)"
@@ -400,15 +457,24 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     // large powers of two at which all components of a slot would fall into the same memory channel.
     if (pixels_per_batch > 2 && pixels_per_batch % 2 == 0) pixels_per_batch--;
     const uint64_t ns = (uint64_t)(pixels_per_batch * spp);
-    // k_conn_gen's waves take the shadow queue in pieces and may each leave one partly unused: one workgroup per 4096
-    // slots (at most four per compute unit) keeps that below an eighth of an entry per slot
-    {
+    // k_connect's waves take the shadow queue in pieces and may each leave one partly unused: one workgroup per 4096 slots
+    // (at most four per compute unit, and never so many that those pieces would take more than a quarter of the queue)
+    uint64_t shadow_cap = 0;
+    if (conn_queue) {
         uint64_t blocks = ns / 4096;
-        if (blocks < 1) blocks = 1;
+        const uint64_t by_queue = (uint64_t)((double)ns * cap_per_slot) / (4ull * cfg.conn_waves * cfg.conn_chunk);
+        if (blocks > by_queue) blocks = by_queue;
         if (blocks > (uint64_t)ctx->cu_count * 4) blocks = (uint64_t)ctx->cu_count * 4;
+        if (blocks < 1) blocks = 1;
         cfg.conn_blocks = (uint32_t)blocks;
+        uint64_t pass_pairs = 0;
+        uint32_t passes = 1;
+        conn_plan(ns, cfg.conn_blocks, shadow_cap, pass_pairs, passes);
+        if (passes > max_passes) return fail(BDPT_ERR_UNSUPPORTED, "internal: connection passes exceed their counters");
+        if (shadow_cap >= ((uint64_t)1 << 32)) return fail(BDPT_ERR_UNSUPPORTED, "internal: shadow queue larger than its 32-bit indices");
+        cfg.conn_passes = passes;
+        cfg.conn_pass_pairs = pass_pairs;
     }
-    const uint64_t shadow_cap = connections ? ns * shadow_per_slot + (uint64_t)cfg.conn_blocks * kConnSlackPerBlock : 0;
     const int64_t n_batches = (n_owned + pixels_per_batch - 1) / pixels_per_batch;
     const int n_streams = (int)(n_batches < want_streams ? n_batches : want_streams);
 
@@ -417,11 +483,13 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     auto take = [&off](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
     const size_t o_ray = take(ns * 6 * 8), o_thr = take(ns * 3 * 8), o_hit = take(ns * 8), o_res = take(ns * 3 * 8);
     const size_t o_tri = take(ns * 4), o_ctr = take(ns * 4), o_cnt = take(ns * 4);
-    const size_t o_q0 = take(ns * 4), o_q1 = take(ns * 4), o_cq = take(ns * 4);
+    const size_t o_q0 = take(ns * 4), o_q1 = take(ns * 4), o_cq = take(scene->ordered ? ns * 4 : 0);
     const uint64_t ns_grouped = (ns + kVtxGroup - 1) / kVtxGroup * kVtxGroup;      // whole groups of slots
-    const size_t o_vtx = take(ns_grouped * vslots * rec_doubles * 8), o_vis = take(ns * vis_words * 8), o_sh = take(shadow_cap * 8 * 8);
-    const size_t o_contrib = take(ns_grouped * kept_per_slot * 3 * 8);
+    const size_t o_vtx = take(ns_grouped * vslots * rec_doubles * 8), o_sh = take(shadow_cap * 7 * 8), o_shvis = take(shadow_cap);
+    const size_t o_contrib = take(cfg.own_test ? shadow_cap * 3 * 8 : 0), o_pair = take(conn_queue && !cfg.own_test ? shadow_cap * 4 : 0);
     const size_t o_first = take(first_leaf ? shadow_cap * 4 : 0);
+    const size_t o_ef = take(conn_queue ? ns * 4 : 0), o_ec = take(conn_queue ? ns * 4 : 0);
+    const size_t o_tiles = take(conn_queue ? (ns / kConnTile + 2) * 8 : 0), o_bounds = take((max_passes + 2) * 4);
     const size_t o_counters = take(n_counters * 4);
     // Measured: the batches in flight run 2.5 % faster when their workspaces lie at least ~30 GB apart in the
     // allocation than when they are neighbours (a total that large without the spacing does not help).  A frame big
@@ -475,12 +543,15 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         wb.counts = reinterpret_cast<uint32_t*>(base + o_cnt);
         wb.queue[0] = reinterpret_cast<uint32_t*>(base + o_q0); wb.queue[1] = reinterpret_cast<uint32_t*>(base + o_q1);
         wb.conn_queue = reinterpret_cast<uint32_t*>(base + o_cq);
-        wb.vtx = reinterpret_cast<double*>(base + o_vtx); wb.vis = reinterpret_cast<unsigned long long*>(base + o_vis);
-        wb.contrib = reinterpret_cast<double*>(base + o_contrib);
+        wb.vtx = reinterpret_cast<double*>(base + o_vtx);
+        wb.contrib = cfg.own_test ? reinterpret_cast<double*>(base + o_contrib) : nullptr;
         wb.shadow = reinterpret_cast<double*>(base + o_sh); wb.counters = reinterpret_cast<uint32_t*>(base + o_counters);
+        wb.sh_vis = reinterpret_cast<uint8_t*>(base + o_shvis); wb.sh_pair = reinterpret_cast<uint32_t*>(base + o_pair);
         wb.shadow_first = first_leaf ? reinterpret_cast<uint32_t*>(base + o_first) : nullptr;
-        wb.ns = ns; wb.shadow_cap = shadow_cap; wb.vis_words = vis_words;
-        wb.vtx_words = (uint32_t)(vslots * rec_doubles); wb.contrib_words = (uint32_t)(kept_per_slot * 3);
+        wb.ent_first = reinterpret_cast<uint32_t*>(base + o_ef); wb.ent_count = reinterpret_cast<uint32_t*>(base + o_ec);
+        wb.tile_pairs = reinterpret_cast<unsigned long long*>(base + o_tiles); wb.pass_bounds = reinterpret_cast<uint32_t*>(base + o_bounds);
+        wb.ns = ns; wb.shadow_cap = shadow_cap;
+        wb.vtx_words = (uint32_t)(vslots * rec_doubles);
         wb.ray_len_ptr = nullptr;
         wb.ray_len = ray_len;
     }
@@ -522,10 +593,10 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         auto eye_cursor = [&](int k) { return C + 8 + 2 * k + 1; };
         auto light_count = [&](int k) { return C + 8 + 2 * depth + 2 * k; };
         auto light_cursor = [&](int k) { return C + 8 + 2 * depth + 2 * k + 1; };
-        auto shadow_count = [&](int a) { return C + 8 + 4 * depth + 2 * a; };
-        auto shadow_cursor = [&](int a) { return C + 8 + 4 * depth + 2 * a + 1; };
-        auto eye_redo = [&](int k) { return C + 8 + 6 * depth + k; };
-        auto light_redo = [&](int k) { return C + 8 + 7 * depth + k; };
+        auto eye_redo = [&](int k) { return C + 8 + 4 * depth + k; };
+        auto light_redo = [&](int k) { return C + 8 + 5 * depth + k; };
+        auto shadow_count = [&](int p) { return C + 8 + 6 * depth + 2 * p; };
+        auto shadow_cursor = [&](int p) { return C + 8 + 6 * depth + 2 * p + 1; };
         uint32_t* conn_count = C;
 
         WfBatch b;
@@ -577,12 +648,18 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
             }
         }
         // connections: camera.h:316-320
-        if (connections) HIP_TRY(wf_conn_prepare(gcam, wb, b, conn_count, cfg, stats, st));
-        if (connections && cfg.ordered) HIP_TRY(wf_conn_ordered(scene->dev, gcam, wb, b, conn_count, cfg, st));
-        for (int a = 0; a < depth && connections && !cfg.ordered; a++) {
-            HIP_TRY(wf_conn_gen(scene->dev, gcam, wb, a, conn_count, shadow_count(a), cfg, stats, st));
-            { int rc = timed(1, st, [&] { return wf_occlude(scene->dev, wb, shadow_count(a), 0, shadow_cursor(a), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
-            HIP_TRY(wf_conn_accum(scene->dev, gcam, wb, a, conn_count, cfg, st));
+        if (connections && cfg.ordered) {
+            HIP_TRY(wf_conn_prepare(gcam, wb, b, conn_count, cfg, stats, st));
+            HIP_TRY(wf_conn_ordered(scene->dev, gcam, wb, b, conn_count, cfg, st));
+        }
+        if (conn_queue) {
+            HIP_TRY(wf_conn_count(wb, n_slots, cfg, stats, st));
+            HIP_TRY(wf_conn_plan(wb, n_slots, cfg, st));
+            for (int p = 0; p < (int)cfg.conn_passes; p++) {
+                HIP_TRY(wf_connect(scene->dev, gcam, wb, n_slots, p, shadow_count(p), cfg, stats, st));
+                { int rc = timed(1, st, [&] { return wf_occlude(scene->dev, wb, shadow_count(p), 0, shadow_cursor(p), cfg, stats, st); }); if (rc != BDPT_OK) return rc; }
+                HIP_TRY(wf_conn_add(scene->dev, gcam, wb, n_slots, p, cfg, st));
+            }
         }
         HIP_TRY(wf_resolve(gcam, wb, b, d_fb, cfg, st));
     }
@@ -620,8 +697,10 @@ int render_impl(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_camera_st
     // path, which also takes over when the four-wide hierarchy is deeper than the pipeline's traversal stack.
     // Everything else runs the wavefront pipeline unless the caller asks otherwise.
     const bool cx_single = scene->composite && (scene->ordered ? (stats_mode != 0 || (p->flags & BDPT_RENDER_MEGAKERNEL) || unidirectional)
-                                                               : (!scene->pipeline || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || unidirectional || !pipeline_can_walk(scene)));
-    const bool single_kernel = cx_single || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || (!scene->ordered && !pipeline_can_walk(scene));
+                                                               : (!scene->pipeline || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || unidirectional || !pipeline_can_walk(scene) ||
+                                                                  !pipeline_can_connect(scene, cam->max_depth)));
+    const bool single_kernel = cx_single || stats_mode == 1 || (p->flags & BDPT_RENDER_MEGAKERNEL) || (!scene->ordered && !pipeline_can_walk(scene)) ||
+                               (!scene->ordered && !unidirectional && !pipeline_can_connect(scene, cam->max_depth));
     if (cx_single && fixed_ws) return fail(BDPT_ERR_UNSUPPORTED, "these flags put a composite scene on the single-kernel path, which allocates");
     if (fixed_ws && (single_kernel || time_stages))
         return fail(BDPT_ERR_UNSUPPORTED, pipeline_can_walk(scene)
@@ -709,14 +788,14 @@ int visible_pipeline(bdpt_context* ctx, const bdpt_scene* scene, const double* d
     const uint64_t piece = n < kQueryPiece ? n : kQueryPiece;
     size_t off = 0;
     auto take = [&off](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
-    const size_t o_sh = take(piece * 8 * 8), o_vis = take(piece * 8), o_cur = take(256);
+    const size_t o_sh = take(piece * 7 * 8), o_vis = take(piece), o_cur = take(256);
     { int rc = ensure_query_ws(ctx, off); if (rc != BDPT_OK) return rc; }
     char* base = static_cast<char*>(ctx->query_ws);
     WfBuffers wb{};
     wb.shadow = reinterpret_cast<double*>(base + o_sh);
-    wb.vis = reinterpret_cast<unsigned long long*>(base + o_vis);
+    wb.sh_vis = reinterpret_cast<uint8_t*>(base + o_vis);
     uint32_t* cursor = reinterpret_cast<uint32_t*>(base + o_cur);
-    wb.ns = piece; wb.shadow_cap = piece; wb.vis_words = 1;
+    wb.ns = piece; wb.shadow_cap = piece;
     for (uint64_t first = 0; first < n; first += piece) {
         const uint32_t m = (uint32_t)(n - first < piece ? n - first : piece);
         HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), stream));

@@ -23,21 +23,28 @@ struct WfBuffers {
     double* result;       // [3][ns]  radiance of the sample
     uint32_t* counts;     // [ns]     n_eye | n_light << 12 | flags << 24
     double* vtx;          // [ns / kVtxGroup][2*depth][10][kVtxGroup]  stored (non-delta) path vertices: eye 0.., light depth..
-    unsigned long long* vis;   // [vis_words][ns]  visibility bits of the pairs (a, b = 0..) of the current eye vertex a
     uint32_t* queue[2];   // [ns]     live-sample queues (ping-pong)
-    uint32_t* conn_queue; // [ns]     samples that have both eye and light vertices
-    double* contrib;      // [ns / kVtxGroup][depth][3][kVtxGroup]  what pair (a, b) of the current eye vertex a adds if its shadow ray is clear (scenes staged in LDS only)
-    double* shadow;       // [8][shadow_cap]  shadow rays: origin, direction, max_t, tag (slot, b)
+    uint32_t* conn_queue; // [ns]     scenes with media only: samples that have both eye and light vertices
+    // Connection stage (camera.h:316-320).  The pairs (eye vertex a, light vertex b) of a range of samples that need a
+    // visibility ray are queue entries; the entries of ONE sample are contiguous and in the reference's pair order (a
+    // outer, b inner), so the sample's sum is formed by walking them.
+    double* shadow;       // [7][shadow_cap]  shadow rays: origin, direction, max_t (negative: an unused entry)
+    uint8_t* sh_vis;      // [shadow_cap]  1: the entry's shadow ray came back clear (cleared when the entry is made)
+    uint32_t* sh_pair;    // [shadow_cap]  a << 12 | b of the entry's pair
     uint32_t* shadow_first;   // [shadow_cap]  position in SceneDev::xtris of the triangle a shadow ray's walk tests first (the
                               // one its far end lies on), or null: every walk starts at the root
+    double* contrib;      // [3][shadow_cap]  what the entry's pair adds if its ray is clear (scenes whose connection kernel
+                          // tests the far end's own triangle), or null: clear pairs are evaluated again when they are added
+    uint32_t* ent_first;  // [ns]     first queue entry of the sample's pairs in the current pass
+    uint32_t* ent_count;  // [ns]     number of its entries
+    unsigned long long* tile_pairs;   // [ns / kConnTile + 1]  candidate pairs of each tile of slots, then their running sums
+    uint32_t* pass_bounds;    // [passes + 1]  the tiles of pass p: pass_bounds[p] .. pass_bounds[p + 1]
     uint32_t* counters;   // queue sizes and work-distribution cursors, zeroed once per batch
     const float* ray_len_ptr;  // upper bound of |direction| over the closest-hit rays: *ray_len_ptr, or ray_len when null
     float ray_len;
     uint64_t ns;
     uint64_t shadow_cap;
-    uint32_t vis_words;
     uint32_t vtx_words;       // words of `vtx` per slot (records x 10, or x 13 in a scene with textures)
-    uint32_t contrib_words;   // words of `contrib` per slot (depth x 3)
 };
 
 // slots per group of the vertex and contribution arrays (see slot_store in wavefront.hip)
@@ -64,8 +71,8 @@ struct WfBatch {
     int64_t n_owned;
 };
 
-// unused shadow-queue entries one workgroup of k_conn_gen can leave behind (waves x entries a wave takes at a time)
-constexpr uint32_t kConnSlackPerBlock = 4 * 128;
+// slots per tile of the connection stage's planning (k_conn_count / k_conn_plan): one group of vertex records
+constexpr uint32_t kConnTile = 64;
 
 struct WfLaunchCfg {
     int persistent_blocks;    // grid of the persistent traversal kernels
@@ -76,11 +83,19 @@ struct WfLaunchCfg {
     bool ordered;         // the scene holds a constant_medium: rays are traced in the reference's own order (k_walk_ordered,
                           // k_conn_ordered) and the shading kernels know the isotropic phase function (implies `textured`)
     bool textured;        // some material carries a texture (implies `instanced`: those kernels, with vertex records of kVtxDoublesTextured words)
-    uint32_t conn_blocks; // workgroups of k_conn_gen (each may leave up to kConnSlackPerBlock unused entries in the shadow queue)
-    bool own_test;        // k_conn_gen tests the light vertex's own triangle (from tables in LDS) and keeps the pairs' contributions
+    // connection stage: k_connect stages the vertex records of a run of samples in LDS (conn_rec_budget records per wave)
+    // and takes the shadow queue conn_chunk entries at a time; every wave may leave one such piece partly unused
+    uint32_t conn_blocks;     // workgroups of k_connect
+    uint32_t conn_waves;      // waves per workgroup (4; fewer when a sample's 2 x depth records need a larger staging area)
+    uint32_t conn_rec_budget; // vertex records a wave stages at a time (>= 2 x depth)
+    uint32_t conn_chunk;      // queue entries a wave takes at a time (>= the pairs of one sample, depth x depth)
+    uint32_t conn_passes;     // passes the host launches; pass p handles the tiles pass_bounds[p] .. pass_bounds[p + 1]
+    unsigned long long conn_pass_pairs;   // most candidate pairs the planner gives one pass (what the queue holds for certain)
+    bool own_test;        // k_connect tests the light vertex's own triangle (from tables in LDS) and keeps the pairs' contributions
     size_t lds_bytes;
     size_t ref_tree_bytes;    // LDS copy of the reference's tree (nodes + parents) for scenes staged in LDS
-    size_t conn_lds_bytes;    // dynamic LDS of k_conn_gen's own-triangle variant: that copy, then triangles, grazing thresholds, leaf nodes
+    size_t conn_lds_bytes;    // dynamic LDS of k_connect: the waves' staging areas, then (own_test) that copy, triangles,
+                              // grazing thresholds, leaf nodes
     int refill_threshold;     // a wave fetches new rays when at least this many of its lanes are idle
     int leaf_threshold;       // lanes of a wave that must stand at a leaf before the wave turns to triangle tests
     int leaf_inner;           // ... and it stays with the triangles of those leaves while this many lanes have one left
@@ -109,10 +124,17 @@ hipError_t wf_shade_unidirectional(const SceneDev& sc, const GpuCamera& cam, con
                                    bool last_level, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
 hipError_t wf_gen_light(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* queue_out,
                         uint32_t* count_out, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
+// connection stage, in this order: candidate pairs per tile of slots; the passes' tile ranges; then per pass the
+// shadow rays of its pairs (wf_connect), their traversal (wf_occlude with the pass's queue size) and the sums (wf_conn_add)
+hipError_t wf_conn_count(const WfBuffers& wb, uint32_t n_slots, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
+hipError_t wf_conn_plan(const WfBuffers& wb, uint32_t n_slots, const WfLaunchCfg& cfg, hipStream_t st);
+hipError_t wf_connect(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, uint32_t n_slots, int pass, uint32_t* shadow_count,
+                      const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
+hipError_t wf_conn_add(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, uint32_t n_slots, int pass, const WfLaunchCfg& cfg,
+                       hipStream_t st);
+// scenes with media: the samples that have vertices on both sides (k_conn_ordered's queue)
 hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, uint32_t* conn_count,
                            const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
-hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
-                       uint32_t* shadow_count, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
 // scenes with media: closest-hit walk in the reference's order for the rays of a queue, and the whole connection stage
 hipError_t wf_walk_ordered(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const uint32_t* queue,
                            const uint32_t* count_ptr, uint32_t count_imm, const WfLaunchCfg& cfg, hipStream_t st);
@@ -121,8 +143,6 @@ hipError_t wf_conn_ordered(const SceneDev& sc, const GpuCamera& cam, const WfBuf
 // number of queue entries: *shadow_count, or count_imm when shadow_count is null
 hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t count_imm, uint32_t* cursor,
                       const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st);
-hipError_t wf_conn_accum(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
-                         const WfLaunchCfg& cfg, hipStream_t st);
 hipError_t wf_resolve(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, double* fb, const WfLaunchCfg& cfg,
                       hipStream_t st);
 
@@ -130,7 +150,8 @@ hipError_t wf_resolve(const GpuCamera& cam, const WfBuffers& wb, const WfBatch& 
 // far-end ties and the reference's own box walk (see g_tie_counts in wavefront.hip); hipErrorNotSupported otherwise.
 hipError_t wf_tie_counts(unsigned long long* out8, bool reset);
 
-// sets the LDS limit of the traversal kernels for this launch shape and reports how many workgroups fit a CU
+// sets the LDS limits of the traversal and connection kernels for this launch shape and reports how many traversal
+// workgroups fit a CU
 hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu);
 
 // Table of the image rows a render call owns: rows j of [y0, y1) with (j / shard_rows) % shard_count == shard_index,
@@ -144,7 +165,7 @@ hipError_t wf_fill_rows(int32_t* rows, int y0, int y1, int shard_rows, int shard
 // also raises *ray_len_out (zeroed by the caller) to the largest |direction|
 hipError_t wf_rays_in(const double* rays, uint32_t n, const WfBuffers& wb, double* tmax_out, float* ray_len_out, hipStream_t st);
 hipError_t wf_hits_out(const SceneDev& sc, const double* rays, uint32_t n, const WfBuffers& wb, double* hits, hipStream_t st);
-// pairs: n x 6 doubles (a, b) -> shadow-ray queue entries 0..n-1 (pair k answers in bit 0 of wb.vis[k]);  out: n bytes
+// pairs: n x 6 doubles (a, b) -> shadow-ray queue entries 0..n-1 (pair k answers in wb.sh_vis[k]);  out: n bytes
 hipError_t wf_pairs_in(const double* pairs, uint32_t n, const WfBuffers& wb, hipStream_t st);
 hipError_t wf_visible_out(const WfBuffers& wb, uint32_t n, uint8_t* out, hipStream_t st);
 

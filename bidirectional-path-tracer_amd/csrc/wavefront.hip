@@ -30,8 +30,6 @@ constexpr int kStageBlock = 256;
 constexpr int kStagePerThread = 4;
 constexpr int kStageTile = kStageBlock * kStagePerThread;
 constexpr int kStageWaves = kStageBlock / 64;
-constexpr uint32_t kShadowChunk = 128;
-static_assert(kConnSlackPerBlock == kStageWaves * kShadowChunk, "the host sizes the shadow queue with this");
 BDPT_DEV void tile_append(const bool (&flag)[kStagePerThread], const uint32_t (&value)[kStagePerThread], uint32_t* queue,
                           uint32_t* count, uint32_t* s_wave, uint32_t* s_base) {
     unsigned long long m[kStagePerThread];
@@ -104,11 +102,6 @@ BDPT_DEV uint32_t slot_vertex_info(const WfBuffers& wb, uint32_t slot, int rec) 
     const VertexStore st = slot_store(wb, slot);
     return (uint32_t)__double_as_longlong(st.ws[((uint64_t)rec * (TEX ? kVtxDoublesTextured : kVtxDoubles) + 9) * st.stride + st.g]);
 }
-// kept contribution of the pair with light vertex `bi` (three words kVtxGroup apart), same grouping
-BDPT_DEV double* slot_contrib(const WfBuffers& wb, uint32_t slot, uint32_t bi) {
-    return wb.contrib + (uint64_t)(slot / kVtxGroup) * ((uint64_t)kVtxGroup * wb.contrib_words) + (uint64_t)bi * 3u * kVtxGroup + slot % kVtxGroup;
-}
-
 // ------------------------------------------------------------------ camera rays
 __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb, WfBatch b) {
     const uint32_t spp = (uint32_t)(cam.sqrt_spp * cam.sqrt_spp);
@@ -273,7 +266,6 @@ constexpr int32_t kPop = (int32_t)0x80000000;   // neither an interior index (>=
 
 template <class NodeT>
 struct TreeMem {
-    static constexpr bool kKeepTag = true;     // (see traverse_queue: registers are not the limit of this variant)
     const NodeT* wn;          // global or LDS copy
     const GpuTri* st;
     BDPT_DEV NodeT wnode(int32_t i) const { return wn[i]; }
@@ -283,7 +275,6 @@ struct TreeMem {
 // Large scenes: the records nearest the root come from LDS, the deeper ones from global memory.
 template <class NodeT>
 struct TopLdsMem {
-    static constexpr bool kKeepTag = false;
     const NodeT* lds;         // first n_lds records
     const NodeT* wn;
     const GpuTri* st;
@@ -493,7 +484,7 @@ BDPT_DEV RefTree stage_ref_tree(const SceneDev& sc, unsigned char* dst) {
 // other, so mixing the two in one iteration would run the (long) triangle test for a handful of lanes
 // every time.  Lanes that reach a leaf wait until `leaf_threshold` lanes of the wave have one (or no lane
 // has an interior record left).  SHADOW: rays come from the shadow queue, the walk stops at the first
-// accepted triangle and a clear ray sets its pair's visibility bit.
+// accepted triangle and a clear ray sets its queue entry's flag.
 // INSTANCED: an entry of the triangle table may belong to an object; its test then takes the ray as the object's mesh
 // sees it (the reference's translate::hit / rotate_y::hit in front of triangle::hit), everything else is unchanged -
 // the ray parameter t is the same number in both coordinate systems.
@@ -521,12 +512,8 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
         else stk_quad[sp - kLdsStack] = e;
         sp++;
     };
-    // visibility rays: the pair a ray belongs to.  The variant that walks records in global memory keeps only the queue
-    // entry and reads the tag again when the ray is done: one register less, which is what lets two waves of a shading
-    // kernel fit beside three workgroups of it; the variant with the whole scene in LDS has that register to spare and
-    // is spared the extra load on its exit path.
+    // visibility rays: the queue entry of the ray (a clear ray sets the entry's flag)
     uint32_t entry = 0;
-    unsigned long long tag = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     double closest = 0;
     RayF32 rf = {};
@@ -571,8 +558,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                         o = mk(wb.shadow[k], wb.shadow[cap + k], wb.shadow[2 * cap + k]);
                         d = mk(wb.shadow[3 * cap + k], wb.shadow[4 * cap + k], wb.shadow[5 * cap + k]);
                         tmax0 = wb.shadow[6 * cap + k];
-                        if (Mem::kKeepTag) tag = (unsigned long long)__double_as_longlong(wb.shadow[7 * cap + k]);
-                        else entry = k;
+                        entry = k;
                     } else {
                         slot = queue ? queue[k] : k;
                         const uint64_t ns = wb.ns;
@@ -725,12 +711,7 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
         }
         if (done) {
             if (SHADOW) {
-                if (h.tri < 0) {       // nothing in the way: the pair is visible
-                    if (!Mem::kKeepTag) tag = (unsigned long long)__double_as_longlong(wb.shadow[7 * wb.shadow_cap + entry]);
-                    const uint32_t s = (uint32_t)(tag >> 16);
-                    const uint32_t bidx = (uint32_t)(tag & 0xFFFFu);
-                    atomicOr(&wb.vis[(uint64_t)(bidx >> 6) * wb.ns + s], 1ull << (bidx & 63u));
-                }
+                if (h.tri < 0) wb.sh_vis[entry] = 1;       // nothing in the way: the pair is visible
             } else {
 #ifdef BDPT_AB_COUNT_REDO
                 if (STATS && redo) n_redo++;
@@ -1337,6 +1318,77 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_prepare(GpuCamera cam, WfB
     if (STATS) { flush_wave_counter(&stats[8], draws); flush_wave_counter(&stats[9], samples); }
 }
 
+// ------------------------------------------------------------------ connection stage (camera.h:316-320, 440-475)
+// Candidate pairs (eye vertices x light vertices) of every tile of kConnTile slots.  A sample has them when it stored
+// vertices on both sides (a light vertex exists only where the emitter sample was valid and the eye subpath is
+// connectable, see k_gen_light).  Counting modes: the draws and samples of the batch as well.
+static_assert(kConnTile == 64 && kConnTile == kVtxGroup, "one wave counts one tile, and k_connect takes one group of vertex records at a time");
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_conn_count(WfBuffers wb, uint32_t n_slots, unsigned long long* stats) {
+    unsigned long long draws = 0, samples = 0, all_pairs = 0;
+    const uint32_t n_tiles = (n_slots + kConnTile - 1) / kConnTile;
+    const uint32_t n_waves = gridDim.x * (kBlock >> 6);
+    for (uint32_t tile = blockIdx.x * (kBlock >> 6) + (threadIdx.x >> 6); tile < n_tiles; tile += n_waves) {
+        const uint32_t slot = tile * kConnTile + lane_id();
+        unsigned long long sum = 0;
+        if (slot < n_slots) {
+            const uint32_t cnt = wb.counts[slot];
+            sum = (unsigned long long)(cnt & 0xFFFu) * ((cnt >> 12) & 0xFFFu);
+            if (STATS) { draws += wb.ctr[slot]; samples++; }
+        }
+        if (STATS) all_pairs += sum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+        if (lane_id() == 0) wb.tile_pairs[tile] = sum;
+    }
+    if (STATS) { flush_wave_counter(&stats[8], draws); flush_wave_counter(&stats[9], samples); flush_wave_counter(&stats[7], all_pairs); }
+}
+
+// The passes of the connection stage: the tiles are dealt out in order, as many to a pass as the shadow queue holds for
+// certain (`pass_pairs` candidate pairs; one tile never has more).  One workgroup: running sums of the tile counts, then
+// the first tile of every pass by bisection.  Tiles beyond the last pass with work make empty passes.
+__global__ __launch_bounds__(kBlock) void k_conn_plan(WfBuffers wb, uint32_t n_tiles, unsigned long long pass_pairs, uint32_t n_passes) {
+    __shared__ unsigned long long s_sum[kBlock];
+    const uint32_t per = (n_tiles + kBlock - 1) / kBlock;
+    const uint32_t lo = threadIdx.x * per < n_tiles ? threadIdx.x * per : n_tiles;
+    const uint32_t hi = lo + per < n_tiles ? lo + per : n_tiles;
+    unsigned long long mine = 0;
+    for (uint32_t t = lo; t < hi; t++) mine += wb.tile_pairs[t];
+    s_sum[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int k = 0; k < kBlock; k++) { const unsigned long long v = s_sum[k]; s_sum[k] = run; run += v; }
+    }
+    __syncthreads();
+    unsigned long long run = s_sum[threadIdx.x];
+    for (uint32_t t = lo; t < hi; t++) { run += wb.tile_pairs[t]; wb.tile_pairs[t] = run; }       // inclusive running sums
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const volatile unsigned long long* sums = wb.tile_pairs;
+        uint32_t start = 0;
+        wb.pass_bounds[0] = 0;
+        for (uint32_t p = 0; p < n_passes; p++) {
+            uint32_t end = n_tiles;
+            if (start < n_tiles) {
+                const unsigned long long before = start ? sums[start - 1] : 0ull;
+                if (sums[n_tiles - 1] - before > pass_pairs) {
+                    // the largest `end` with sums[end - 1] - before <= pass_pairs (at least one tile: a tile always fits)
+                    uint32_t a = start + 1, b = n_tiles;          // the answer lies in [a, b)
+                    while (a + 1 < b) {
+                        const uint32_t mid = a + (b - a) / 2;
+                        if (sums[mid - 1] - before <= pass_pairs) a = mid; else b = mid;
+                    }
+                    end = a;
+                }
+            }
+            wb.pass_bounds[p + 1] = end;
+            start = end;
+        }
+    }
+}
+
 // What a connection needs of the materials (camera.h:458-469), worked out once per workgroup into LDS instead of once
 // per pair from global memory (two dependent loads in the middle of every pair): the BSDF value of each material and
 // its colour (the radiance of an emitter).  Scenes with more materials than kPairMats read the global table per pair.
@@ -1370,36 +1422,66 @@ BDPT_DEV PairMats stage_pair_mats(const SceneDev& sc, double* lds) {
     return PairMats{lds};
 }
 
-// shadow rays of eye vertex `a` against every light vertex of the sample.  Only pairs that need a ray get a queue
-// entry: a wave takes kShadowChunk entries of the queue at a time (one atomic) and fills them round by round; what
-// is left of its last piece at the end gets a negative max_t, which the traversal skips.
-// The far end point of a shadow ray lies ON a surface at t = max_t, and in most unoccluded pairs rounding makes that
-// surface's own triangle accept (t <= max_t): the reference then calls the pair blocked (camera.h:437).  That
-// triangle is tested here, before any ray exists - it is the light vertex's own triangle, known from the vertex -
-// with the traversal kernel's rules (a hit at the end of the interval counts only if the reference's boxes let it
-// through), so most blocked pairs never become a ray.  "Some triangle accepts and is reachable" does not depend on
-// which such triangle is found first.  Done for scenes whose tables are staged in LDS; on a large scene the test is
-// two dependent loads from random places of global memory per pair, and most of its pairs are blocked by something
-// the traversal finds sooner (measured on a 0.96 M-triangle lattice: 2 361 -> 1 446 Msamples/s with the test, on 10.2 M
-// triangles 1 826 -> 944, on the 51 k-triangle coffee machine 2 859 -> 2 791), so those scenes run the instantiation
-// without it (OWN_TEST = false).
+// A vertex record out of a wave's staging area: lds[field * budget + index]
+template <bool TEX>
+BDPT_DEV Vertex staged_vertex(const double* lds, uint32_t budget, uint32_t idx) {
+    const double* b = lds + idx;
+    Vertex v;
+    v.p = mk(b[0], b[budget], b[2 * budget]);
+    v.n = mk(b[3 * budget], b[4 * budget], b[5 * budget]);
+    v.T = mk(b[6 * budget], b[7 * budget], b[8 * budget]);
+    const unsigned long long w = (unsigned long long)__double_as_longlong(b[9 * budget]);
+    v.info = (uint32_t)w;
+    v.tri = (uint32_t)(w >> 32);
+    v.f = TEX ? mk(b[10 * budget], b[11 * budget], b[12 * budget]) : mk(0, 0, 0);
+    return v;
+}
+
+// The shadow rays of ALL pairs (eye vertex a, light vertex b) of the samples of one pass.
+//
+// Memory.  A wave works on one group of 64 neighbouring slots at a time (the vertex records are laid out in such
+// groups).  It copies the records of a run of those slots into LDS with row loads - one field of one record of up to
+// 64 neighbouring slots is one contiguous piece of memory - and every pair then reads its two vertices from LDS.  A
+// vertex is fetched once however many pairs it takes part in, and no load is a gather.  (Before, a launch per eye
+// vertex read both vertices of every pair with 8-byte gathers from global memory - the light vertices of a sample once
+// per eye vertex - and the texture addresser was busy 84 % of the kernel's time: 150 of the 375 ms a Cornell-box frame
+// spends in kernels.)
+//
+// Pairs.  The pairs of a run of WHOLE samples that together have at most 64 are dealt to the lanes (a sample with more
+// than 64 takes rounds of its own), numbered sample by sample, eye vertex by eye vertex: the reference's order
+// (camera.h:316-320).  Only pairs that need a ray get a queue entry; a round's entries are consecutive, and a wave takes
+// the queue `chunk` entries at a time and never lets the entries of one sample straddle two such pieces (what is left
+// of a piece gets a negative max_t, which the traversal skips).  So the entries of a sample are contiguous and in pair
+// order: ent_first / ent_count are all k_conn_add needs.
+//
+// OWN_TEST (scenes whose tables are staged in LDS): the far end point of a shadow ray lies ON a surface at t = max_t, and
+// in most unoccluded pairs rounding makes that surface's own triangle accept (t <= max_t): the reference then calls the
+// pair blocked (camera.h:437).  That triangle is tested here, before any ray exists - it is the light vertex's own
+// triangle, known from the vertex - with the traversal kernel's rules (a hit at the end of the interval counts only if
+// the reference's boxes let it through), so most blocked pairs never become a ray; most rays that remain come back
+// clear, so what the pair adds (camera.h:471-474) is kept with the entry.  "Some triangle accepts and is reachable"
+// does not depend on which such triangle is found first.  On a large scene the test is two dependent loads from random
+// places of global memory per pair, and most of its pairs are blocked by something the traversal finds sooner (measured
+// on a 0.96 M-triangle lattice: 2 361 -> 1 446 Msamples/s with the test): those scenes start the ray's walk at that
+// triangle instead (WfBuffers::shadow_first) and evaluate the few clear pairs when they are added.
 // TEX: the factors of a pair come from its vertices (Vertex::f), not from the material table.
-template <bool STATS, bool OWN_TEST, bool TEX = false>
-__global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera cam, WfBuffers wb, int a,
-                                                          const uint32_t* conn_count, uint32_t* shadow_count,
-                                                          unsigned long long* stats) {
+template <bool STATS, bool OWN_TEST, bool TEX>
+__global__ __launch_bounds__(kBlock) void k_connect(SceneDev sc, GpuCamera cam, WfBuffers wb, uint32_t n_slots, int pass,
+                                                   uint32_t* shadow_count, uint32_t budget, uint32_t chunk, unsigned long long* stats) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ uint32_t s_wave_off[kStageWaves];
-    __shared__ uint32_t s_prefix[kStageTile + 1];
-    __shared__ uint32_t s_slot[kStageTile];
     __shared__ double s_pair_mats[kPairMats * 6];
+    const uint32_t tile0 = wb.pass_bounds[pass], tile1 = wb.pass_bounds[pass + 1];
+    if (tile0 >= tile1) return;                  // an empty pass: the whole workgroup, before anything is staged
+    constexpr uint32_t W = TEX ? kVtxDoublesTextured : kVtxDoubles;
+    const uint32_t n_waves_block = blockDim.x >> 6;
     const PairMats pmats = stage_pair_mats(sc, s_pair_mats);
     RefTree ref{sc.nodes, sc.node_parent};
     const GpuTri* own_tris = sc.tris;
     const int32_t* own_graze = sc.tri_graze;
     const uint32_t* own_leaf = sc.tri_leaf;
-    if (OWN_TEST) {         // small scene: the reference's tree and the triangle tables the test reads, in LDS
-        unsigned char* at = smem + ((ref_tree_lds_bytes(sc.n_nodes) + 15) & ~(size_t)15);
+    if (OWN_TEST) {         // small scene: the reference's tree and the triangle tables the test reads, in LDS behind the staging areas
+        unsigned char* at0 = smem + (size_t)n_waves_block * budget * W * sizeof(double);
+        unsigned char* at = at0 + ((ref_tree_lds_bytes(sc.n_nodes) + 15) & ~(size_t)15);
         GpuTri* l_tris = reinterpret_cast<GpuTri*>(at);
         int32_t* l_graze = reinterpret_cast<int32_t*>(l_tris + sc.n_tris);
         uint32_t* l_leaf = reinterpret_cast<uint32_t*>(l_graze + sc.n_tris);
@@ -1407,269 +1489,279 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_gen(SceneDev sc, GpuCamera
         uint4* dst = reinterpret_cast<uint4*>(l_tris);
         for (uint32_t k = threadIdx.x; k < sc.n_tris * (uint32_t)(sizeof(GpuTri) / 16); k += blockDim.x) dst[k] = src[k];
         for (uint32_t k = threadIdx.x; k < sc.n_tris; k += blockDim.x) { l_graze[k] = sc.tri_graze[k]; l_leaf[k] = sc.tri_leaf[k]; }
-        ref = stage_ref_tree(sc, smem);        // (ends with a barrier)
+        ref = stage_ref_tree(sc, at0);        // (ends with a barrier)
         own_tris = l_tris; own_graze = l_graze; own_leaf = l_leaf;
     }
     __syncthreads();
     const GrazeBits gbits = graze_bits(sc.bary_margin, 1.0001f);
-    const uint32_t count = *conn_count;
-    const int depth = cam.max_depth;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t depth = (uint32_t)cam.max_depth;
+    const uint32_t lane = lane_id();
+    const uint32_t wave_in_block = threadIdx.x >> 6;
+    double* const lds = reinterpret_cast<double*>(smem) + (size_t)wave_in_block * budget * W;
     const uint64_t cap = wb.shadow_cap;
-    uint32_t n_pairs = 0;
+    const uint32_t slot_end = (uint64_t)tile1 * kConnTile < n_slots ? tile1 * kConnTile : n_slots;
+    const uint32_t n_waves = gridDim.x * n_waves_block;
     uint32_t chunk_next = 0, chunk_end = 0;     // this wave's piece of the shadow queue (the same in all lanes)
-    for (uint32_t tile = blockIdx.x * kStageTile; tile < count; tile += gridDim.x * kStageTile) {
-        // pass 1: how many candidate pairs each entry of the tile has (a thread looks at kStagePerThread neighbours)
-        uint32_t mine[kStagePerThread];
-        uint32_t total = 0;
-#pragma unroll
-        for (int j = 0; j < kStagePerThread; j++) {
-            const uint32_t el = threadIdx.x * kStagePerThread + (uint32_t)j;
-            const uint32_t k = tile + el;
-            mine[j] = 0;
-            if (k < count) {
-                const uint32_t slot = wb.conn_queue[k];
-                s_slot[el] = slot;
-                const uint32_t cnt = wb.counts[slot];
-                if ((uint32_t)a < (cnt & 0xFFFu)) {
-                    const uint32_t n_light = (cnt >> 12) & 0xFFFu;
-                    for (uint32_t w = 0; w < wb.vis_words; w++) wb.vis[(uint64_t)w * wb.ns + slot] = 0ull;
-                    if (STATS) n_pairs += n_light;
-                    // an eye vertex on an emitter has a zero BSDF (material.h:35-37): every pair it forms
-                    // contributes zero whatever the visibility, so no ray is spent on it
-                    const uint32_t info = slot_vertex_info<TEX>(wb, slot, a);
-                    if (!(info & kVtxIsLight)) mine[j] = n_light;
-                }
-            }
-            total += mine[j];
+
+    for (uint32_t group = tile0 * (kConnTile / kVtxGroup) + blockIdx.x * n_waves_block + wave_in_block; (uint64_t)group * kVtxGroup < slot_end;
+         group += n_waves) {
+        const uint32_t slot = group * kVtxGroup + lane;
+        uint32_t ne = 0, nl = 0;
+        if (slot < slot_end) {
+            const uint32_t cnt = wb.counts[slot];
+            ne = cnt & 0xFFFu; nl = (cnt >> 12) & 0xFFFu;
+            if (ne == 0u || nl == 0u) ne = nl = 0u;
         }
-        // workgroup-wide exclusive scan: s_prefix[el] = pairs of the tile's entries before entry el
-        uint32_t incl = total;
+        const uint32_t recs = ne + nl, pairs = ne * nl;
+        uint32_t rsum = recs, psum = pairs;          // inclusive running sums over the lanes
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(incl, off, 64);
-            if ((int)lane_id() >= off) incl += v;
+            const uint32_t r = __shfl_up(rsum, off, 64), p = __shfl_up(psum, off, 64);
+            if ((int)lane >= off) { rsum += r; psum += p; }
         }
-        if (lane_id() == 63) s_wave_off[wave] = incl;
-        __syncthreads();
-        uint32_t run = incl - total;
-        for (uint32_t w = 0; w < wave; w++) run += s_wave_off[w];
+        uint32_t my_first = 0, my_count = 0;
+        if (__shfl(psum, 63, 64) != 0u) {
+            const double* const ws = wb.vtx + (uint64_t)group * ((uint64_t)kVtxGroup * wb.vtx_words) + lane;
+            uint32_t s0 = 0;
+            while (s0 < 64u) {
+                // the slots [s0, s1) whose records fit the staging area together (one slot always does)
+                const uint32_t r0 = s0 ? __shfl(rsum, (int)s0 - 1, 64) : 0u;
+                const uint32_t s1 = s0 + (uint32_t)__builtin_popcountll(__ballot(lane >= s0 && rsum - r0 <= budget));
+                const uint32_t p_before = s0 ? __shfl(psum, (int)s0 - 1, 64) : 0u;
+                const bool staged = lane >= s0 && lane < s1;
+                const uint32_t base = rsum - recs - r0;           // index of the slot's first record (eye vertices, then light vertices)
+                if (__shfl(psum, (int)s1 - 1, 64) != p_before) {
+                    uint32_t most = staged ? recs : 0u;
 #pragma unroll
-        for (int j = 0; j < kStagePerThread; j++) { s_prefix[threadIdx.x * kStagePerThread + (uint32_t)j] = run; run += mine[j]; }
-        if (threadIdx.x == kStageBlock - 1) s_prefix[kStageTile] = run;
-        __syncthreads();
-        const uint32_t n_tile_pairs = s_prefix[kStageTile];
-        // pass 2: the pairs of the tile, one per thread and round whatever entry they belong to - the samples of a
-        // tile have eye and light subpaths of all lengths, and a loop per entry would leave most lanes of a wave idle
-        // (measured in a Cornell box: 12 of 64 lanes at work).  Pairs are numbered entry by entry: a wave then works
-        // on a handful of neighbouring samples and uses up the cache lines it touches.  Ordering the entries of the
-        // tile by their number of pairs first (stable counting sort in LDS) - to give a wave one light vertex of 64
-        // samples at a time, or one entry per lane with equally long loops - was slower (k_conn_gen 150 -> 208 and
-        // 195 ms per Cornell-512 frame): the samples a wave touches are then spread over the tile, and the other
-        // words of their cache lines are needed again only after the lines are gone.
-        for (uint32_t p0 = 0; p0 < n_tile_pairs; p0 += kStageBlock) {
-            const uint32_t p = p0 + threadIdx.x;
-            bool emit = false;
-            PairGeom g;
-            uint32_t slot = 0, bi = 0, lv_tri = 0;
-            if (p < n_tile_pairs) {
-                uint32_t el = 0;                // the last entry whose first pair is not after p
+                    for (int off = 32; off > 0; off >>= 1) { const uint32_t v = __shfl_xor(most, off, 64); most = v > most ? v : most; }
+                    for (uint32_t r = 0; r < most; r++) {
+                        if (staged && r < recs) {
+                            const uint32_t rec = r < ne ? r : depth + (r - ne);
+                            const double* src = ws + (uint64_t)rec * W * kVtxGroup;
 #pragma unroll
-                for (uint32_t step = kStageTile / 2; step; step >>= 1) el += (s_prefix[el + step] <= p) ? step : 0u;
-                slot = s_slot[el];
-                bi = p - s_prefix[el];
-                const Vertex cv = slot_store(wb, slot).get<TEX>(a);
-                const Vertex lv = slot_store(wb, slot).get<TEX>(depth + (int)bi);
-                lv_tri = lv.tri;
-                const V3 f_cam = TEX ? cv.f : pmats.bsdf(sc, cv.info & kVtxMatMask);   // (an eye vertex on an emitter never gets here)
-                V3 f_light = mk(0, 0, 0);
-                emit = !(len2(f_cam) <= 0) && pair_geometry(cv, lv, g);                                // camera.h:458-460
-                if (emit) { f_light = TEX ? lv.f : pmats.light_factor(sc, lv.info); emit = len2(f_light) > 0; }      // camera.h:462-469
-                if (OWN_TEST && emit) {
-                    GpuTri own = own_tris[lv.tri];
-                    own.material = own_graze[lv.tri];
-                    double t, u, v, det;
-                    if (tri_candidate(own, g.origin, g.dir_unit, 0.001, t, u, v, det) && t <= g.max_t) {
-                        int ask = grazes(own, u, v, t, det, gbits) ? 2 : (nearly_equal(t, g.max_t) ? far_end_tie<true>(own, g.origin, g.dir_unit, g.max_t) : 0);
-#ifdef BDPT_TIE_CHECK
-                        if (!grazes(own, u, v, t, det, gbits)) {
-                            const bool reached = reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t);
-                            tie_check_record(nearly_equal(t, g.max_t), own, g.origin, g.dir_unit, g.max_t, reached);
-                            ask = reached ? 0 : 1;
+                            for (uint32_t f = 0; f < W; f++) lds[f * budget + base + r] = src[f * kVtxGroup];
                         }
+                    }
+                    // rounds: runs [q0, q1) of whole slots with at most 64 pairs together
+                    uint32_t q0 = s0;
+                    while (q0 < s1) {
+                        const uint32_t pq = q0 ? __shfl(psum, (int)q0 - 1, 64) : 0u;
+                        uint32_t q1 = q0 + (uint32_t)__builtin_popcountll(__ballot(lane >= q0 && lane < s1 && psum - pq <= 64u));
+                        if (q1 == q0) q1 = q0 + 1u;                 // a slot with more than 64 pairs: rounds of its own
+                        const uint32_t n_run = __shfl(psum, (int)q1 - 1, 64) - pq;
+                        if (n_run) {
+                            if (chunk_end - chunk_next < n_run) {   // the entries of a slot stay in one piece of the queue
+                                for (uint32_t e = chunk_next + lane; e < chunk_end; e += 64u) wb.shadow[6 * cap + e] = -1.0;
+                                uint32_t got = 0;
+                                if (lane == 0) got = atomicAdd(shadow_count, chunk);
+                                chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                                chunk_end = chunk_next + chunk;
+                            }
+                            // ends of the run's slots in run coordinates, for the owner search: 0 in front of the run, "never" behind it
+                            const uint32_t ends = lane < q0 ? 0u : (lane >= q1 ? 0xFFFFFFFFu : psum - pq);
+                            for (uint32_t first = 0; first < n_run; first += 64u) {
+                                const uint32_t q = first + lane;
+                                const bool active = q < n_run;
+                                uint32_t owner = 0;             // number of lanes whose slot ends at or before q = the slot pair q belongs to
+#pragma unroll
+                                for (uint32_t step = 32; step; step >>= 1) {
+                                    const uint32_t v = __shfl(ends, (int)(owner + step - 1u), 64);
+                                    if (v <= q) owner += step;
+                                }
+                                owner = owner > 63u ? 63u : owner;
+                                const uint32_t o_ne = __shfl(ne, (int)owner, 64), o_nl = __shfl(nl, (int)owner, 64);
+                                const uint32_t o_base = __shfl(base, (int)owner, 64);
+                                const uint32_t o_start = __shfl(psum - pairs, (int)owner, 64) - pq;
+                                bool emit = false;
+                                PairGeom g;
+                                uint32_t a = 0, bi = 0, lv_tri = 0;
+                                V3 kept = mk(0, 0, 0);
+                                if (active) {
+                                    const uint32_t r = q - o_start;
+                                    a = r / (o_nl ? o_nl : 1u);
+                                    bi = r - a * o_nl;
+                                    const Vertex cv = staged_vertex<TEX>(lds, budget, o_base + a);
+                                    // an eye vertex on an emitter has a zero BSDF (material.h:35-37): every pair it forms contributes
+                                    // zero whatever the visibility, so no ray is spent on it
+                                    if (!(cv.info & kVtxIsLight)) {
+                                        const Vertex lv = staged_vertex<TEX>(lds, budget, o_base + o_ne + bi);
+                                        lv_tri = lv.tri;
+                                        const V3 f_cam = TEX ? cv.f : pmats.bsdf(sc, cv.info & kVtxMatMask);
+                                        V3 f_light = mk(0, 0, 0);
+                                        emit = !(len2(f_cam) <= 0) && pair_geometry(cv, lv, g);                                // camera.h:458-460
+                                        if (emit) { f_light = TEX ? lv.f : pmats.light_factor(sc, lv.info); emit = len2(f_light) > 0; }      // camera.h:462-469
+                                        if (OWN_TEST && emit) {
+                                            GpuTri own = own_tris[lv.tri];
+                                            own.material = own_graze[lv.tri];
+                                            double t, u, v, det;
+                                            if (tri_candidate(own, g.origin, g.dir_unit, 0.001, t, u, v, det) && t <= g.max_t) {
+                                                int ask = grazes(own, u, v, t, det, gbits) ? 2 : (nearly_equal(t, g.max_t) ? far_end_tie<true>(own, g.origin, g.dir_unit, g.max_t) : 0);
+#ifdef BDPT_TIE_CHECK
+                                                if (!grazes(own, u, v, t, det, gbits)) {
+                                                    const bool reached = reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t);
+                                                    tie_check_record(nearly_equal(t, g.max_t), own, g.origin, g.dir_unit, g.max_t, reached);
+                                                    ask = reached ? 0 : 1;
+                                                }
 #endif
-                        if (ask == 2) ask = reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t) ? 0 : 1;
-                        if (ask == 0) emit = false;
+                                                if (ask == 2) ask = reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t) ? 0 : 1;
+                                                if (ask == 0) emit = false;
+                                            }
+                                        }
+                                        if (OWN_TEST && emit) kept = pair_contribution(cv, lv, g, f_cam, f_light);
+                                    }
+                                }
+                                const unsigned long long writers = __ballot(emit);
+                                if (emit) {
+                                    const uint64_t e = chunk_next + rank_in_mask(writers);
+                                    wb.shadow[e] = g.origin.x; wb.shadow[cap + e] = g.origin.y; wb.shadow[2 * cap + e] = g.origin.z;
+                                    wb.shadow[3 * cap + e] = g.dir_unit.x; wb.shadow[4 * cap + e] = g.dir_unit.y; wb.shadow[5 * cap + e] = g.dir_unit.z;
+                                    wb.shadow[6 * cap + e] = g.max_t;
+                                    wb.sh_vis[e] = 0;
+                                    if (OWN_TEST) { wb.contrib[e] = kept.x; wb.contrib[cap + e] = kept.y; wb.contrib[2 * cap + e] = kept.z; }
+                                    else {
+                                        wb.sh_pair[e] = (a << 12) | bi;
+                                        if (wb.shadow_first) wb.shadow_first[e] = sc.tri_xpos[lv_tri];
+                                    }
+                                }
+                                // the slots of the run count their entries of this round
+                                if (lane >= q0 && lane < q1) {
+                                    const uint32_t lo = psum - pairs - pq, hi = psum - pq;          // the slot's pairs in run coordinates
+                                    const uint32_t lo_c = lo > first ? lo - first : 0u;
+                                    const uint32_t hi_c = hi > first ? (hi - first < 64u ? hi - first : 64u) : 0u;
+                                    if (hi_c > lo_c) {
+                                        const unsigned long long below_hi = hi_c >= 64u ? ~0ull : ((1ull << hi_c) - 1ull);
+                                        const unsigned long long below_lo = (1ull << lo_c) - 1ull;
+                                        const uint32_t c = (uint32_t)__builtin_popcountll(writers & below_hi & ~below_lo);
+                                        if (c && my_count == 0u) my_first = chunk_next + (uint32_t)__builtin_popcountll(writers & below_lo);
+                                        my_count += c;
+                                    }
+                                }
+                                chunk_next += (uint32_t)__builtin_popcountll(writers);
+                            }
+                        }
+                        q0 = q1;
                     }
                 }
-                if (OWN_TEST && emit) {
-                    // With the test above most rays that are made come back clear: what the pair then adds
-                    // (camera.h:471-474) is kept, and k_conn_accum only adds it.  Without the test most rays
-                    // come back blocked, and recomputing the few clear pairs there is cheaper than keeping
-                    // all of them here (0.96 M-triangle lattice: 2 217 against 2 331 Msamples/s).
-                    const V3 c = pair_contribution(cv, lv, g, f_cam, f_light);
-                    double* cb = slot_contrib(wb, slot, bi);
-                    cb[0] = c.x; cb[kVtxGroup] = c.y; cb[2 * kVtxGroup] = c.z;
-                }
-            }
-            // queue entries for the rays of this round: the wave takes the shadow queue kShadowChunk entries at a time
-            const unsigned long long writers = __ballot(emit);
-            const uint32_t n_new = (uint32_t)__builtin_popcountll(writers);
-            if (n_new) {
-                const uint32_t room = chunk_end - chunk_next;
-                uint32_t fresh = 0;
-                if (n_new > room) {
-                    uint32_t got = 0;
-                    if (lane_id() == 0) got = atomicAdd(shadow_count, kShadowChunk);
-                    fresh = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-                }
-                if (emit) {
-                    const uint32_t r = rank_in_mask(writers);
-                    const uint64_t e = r < room ? (uint64_t)(chunk_next + r) : (uint64_t)(fresh + (r - room));
-                    wb.shadow[e] = g.origin.x; wb.shadow[cap + e] = g.origin.y; wb.shadow[2 * cap + e] = g.origin.z;
-                    wb.shadow[3 * cap + e] = g.dir_unit.x; wb.shadow[4 * cap + e] = g.dir_unit.y; wb.shadow[5 * cap + e] = g.dir_unit.z;
-                    wb.shadow[6 * cap + e] = g.max_t;
-                    wb.shadow[7 * cap + e] = __longlong_as_double((long long)(((unsigned long long)slot << 16) | bi));
-                    if (!OWN_TEST && wb.shadow_first) wb.shadow_first[e] = sc.tri_xpos[lv_tri];
-                }
-                if (n_new > room) { chunk_next = fresh + (n_new - room); chunk_end = fresh + kShadowChunk; }
-                else chunk_next += n_new;
+                s0 = s1;
             }
         }
-        __syncthreads();        // the tables of this tile are done with
+        if (slot < slot_end) { wb.ent_first[slot] = my_first; wb.ent_count[slot] = my_count; }
     }
     // the unused rest of the wave's last piece: entries the traversal skips (negative max_t)
-    for (uint32_t e = chunk_next + lane_id(); e < chunk_end; e += 64u) wb.shadow[6 * cap + e] = -1.0;
-    if (STATS) flush_wave_counter(&stats[7], n_pairs);
+    for (uint32_t e = chunk_next + lane; e < chunk_end; e += 64u) wb.shadow[6 * cap + e] = -1.0;
 }
 
-// adds the contributions of eye vertex `a` in light-vertex order (camera.h:316-320, 471-474).  KEPT: k_conn_gen left
-// the contribution of every pair it made a ray for in wb.contrib; otherwise the clear pairs are evaluated again here.
-template <bool KEPT, bool TEX = false>
-__global__ __launch_bounds__(kBlock) void k_conn_accum(SceneDev sc, GpuCamera cam, WfBuffers wb, int a, const uint32_t* conn_count) {
-    const uint32_t count = *conn_count;
-    const int depth = cam.max_depth;
-    const uint64_t ns = wb.ns;
-    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
-        const uint32_t slot = wb.conn_queue[k];
-        const uint32_t cnt = wb.counts[slot];
-        if ((uint32_t)a >= (cnt & 0xFFFu)) continue;
-        const int n_light = (int)((cnt >> 12) & 0xFFFu);
-        // most samples have no clear pair at this eye vertex: their vertex and radiance are not even read
-        unsigned long long any = 0ull;
-        for (uint32_t w = 0; w < wb.vis_words; w++) any |= wb.vis[(uint64_t)w * ns + slot];
-        if (!any) continue;
-        Vertex cv;
-        if (!KEPT) cv = slot_store(wb, slot).get<TEX>(a);
-        V3 result = mk(wb.result[slot], wb.result[ns + slot], wb.result[2 * ns + slot]);
+// Adds what the clear pairs of the pass's samples contribute, per sample in the order of its queue entries = the
+// reference's pair order (camera.h:316-320, 471-474).  The entries carry the contributions (k_connect<., OWN_TEST>).
+__global__ __launch_bounds__(kBlock) void k_conn_add_kept(WfBuffers wb, uint32_t n_slots, int pass) {
+    const uint32_t tile0 = wb.pass_bounds[pass], tile1 = wb.pass_bounds[pass + 1];
+    if (tile0 >= tile1) return;
+    const uint32_t slot_end = (uint64_t)tile1 * kConnTile < n_slots ? tile1 * kConnTile : n_slots;
+    const uint64_t ns = wb.ns, cap = wb.shadow_cap;
+    for (uint32_t slot = tile0 * kConnTile + blockIdx.x * kBlock + threadIdx.x; slot < slot_end; slot += gridDim.x * kBlock) {
+        const uint32_t cnt = wb.ent_count[slot];
+        if (!cnt) continue;
+        const uint32_t first = wb.ent_first[slot];
+        V3 result = mk(0, 0, 0);
         bool changed = false;
-        for (int bi = 0; bi < n_light; bi++) {
-            const unsigned long long word = wb.vis[(uint64_t)(bi >> 6) * ns + slot];
-            if (!((word >> (bi & 63)) & 1ull)) continue;       // a bit is set only for a pair that had a ray
-            if (KEPT) {
-                const double* cb = slot_contrib(wb, slot, (uint32_t)bi);
-                result = add(result, mk(cb[0], cb[kVtxGroup], cb[2 * kVtxGroup]));
-            } else {
-                const Vertex lv = slot_store(wb, slot).get<TEX>(depth + bi);
-                PairGeom g;
-                V3 f_cam, f_light;
-                if (!pair_geometry(cv, lv, g)) continue;
-                if (TEX) {
-                    f_cam = (cv.info & kVtxIsLight) ? mk(0, 0, 0) : cv.f;
-                    f_light = lv.f;
-                    if (len2(f_cam) <= 0 || !(len2(f_light) > 0)) continue;
-                } else if (!pair_factors(sc, cv, lv, f_cam, f_light)) continue;
-                result = add(result, pair_contribution(cv, lv, g, f_cam, f_light));
-            }
-            changed = true;
+        for (uint32_t e = first; e < first + cnt; e++) {
+            if (!wb.sh_vis[e]) continue;
+            // most samples have no clear pair: their radiance is not even read
+            if (!changed) { result = mk(wb.result[slot], wb.result[ns + slot], wb.result[2 * ns + slot]); changed = true; }
+            result = add(result, mk(wb.contrib[e], wb.contrib[cap + e], wb.contrib[2 * cap + e]));
         }
         if (changed) { wb.result[slot] = result.x; wb.result[ns + slot] = result.y; wb.result[2 * ns + slot] = result.z; }
     }
 }
 
-// The same for scenes whose clear pairs are evaluated again here (k_conn_accum<false>), one PAIR per lane.  Few samples
-// have a clear pair at a given eye vertex, so with one sample per lane nearly every wave ran the whole pair evaluation
-// for a handful of its lanes.  A wave numbers the clear pairs of its 64 samples (prefix sum of the bit counts), lane l
-// evaluates pair c0 + l whatever sample it belongs to (owner found by a search over the prefix sums, all through lane
-// shuffles), and each sample's lane then collects its own pairs' values in light-vertex order - the additions are the
-// reference's, in the reference's order.  For depths up to 64 (one word of visibility bits per sample).
+// The same for scenes whose clear pairs are evaluated here, one PAIR per lane.  Few samples have a clear pair, so with
+// one sample per lane nearly every wave would run the whole pair evaluation for a handful of its lanes.  A wave numbers
+// the clear entries of its 64 samples (prefix sum of the bit counts), lane l evaluates clear entry c0 + l whatever
+// sample it belongs to (owner found by a search over the prefix sums, all through lane shuffles), and each sample's lane
+// then collects its own pairs' values in entry order - the additions are the reference's, in the reference's order.
+// A sample's entries are looked at 64 at a time.
 template <bool TEX>
-__global__ __launch_bounds__(kBlock) void k_conn_accum_pairs(SceneDev sc, GpuCamera cam, WfBuffers wb, int a, const uint32_t* conn_count) {
-    const uint32_t count = *conn_count;
+__global__ __launch_bounds__(kBlock) void k_conn_add_pairs(SceneDev sc, GpuCamera cam, WfBuffers wb, uint32_t n_slots, int pass) {
+    const uint32_t tile0 = wb.pass_bounds[pass], tile1 = wb.pass_bounds[pass + 1];
+    if (tile0 >= tile1) return;
+    const uint32_t slot_end = (uint64_t)tile1 * kConnTile < n_slots ? tile1 * kConnTile : n_slots;
     const int depth = cam.max_depth;
     const uint64_t ns = wb.ns;
     const uint32_t lane = lane_id();
-    for (uint32_t k0 = blockIdx.x * kBlock + (threadIdx.x & ~63u); k0 < count; k0 += gridDim.x * kBlock) {     // (the same for all lanes of a wave)
-        const uint32_t k = k0 + lane;
-        uint32_t slot = 0;
-        unsigned long long bits = 0ull;
-        if (k < count) {
-            slot = wb.conn_queue[k];
-            const uint32_t cnt = wb.counts[slot];
-            if ((uint32_t)a < (cnt & 0xFFFu)) {
-                const uint32_t n_light = (cnt >> 12) & 0xFFFu;
-                bits = wb.vis[slot] & (n_light >= 64u ? ~0ull : ((1ull << n_light) - 1ull));     // a bit is set only for a pair that had a ray
-            }
-        }
-        const uint32_t np = (uint32_t)__builtin_popcountll(bits);
-        uint32_t incl = np;
+    for (uint32_t k0 = tile0 * kConnTile + blockIdx.x * kBlock + (threadIdx.x & ~63u); k0 < slot_end; k0 += gridDim.x * kBlock) {     // (the same for all lanes of a wave)
+        const uint32_t slot = k0 + lane;
+        uint32_t cnt = 0, first = 0;
+        if (slot < slot_end) { cnt = wb.ent_count[slot]; first = wb.ent_first[slot]; }
+        uint32_t most = cnt;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(incl, off, 64);
-            if ((int)lane >= off) incl += v;
-        }
-        const uint32_t excl = incl - np;
-        const uint32_t n_pairs = __shfl(incl, 63, 64);
-        if (n_pairs == 0) continue;
-        uint32_t max_np = np;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const uint32_t v = __shfl_xor(max_np, off, 64); max_np = v > max_np ? v : max_np; }
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t v = __shfl_xor(most, off, 64); most = v > most ? v : most; }
+        if (!most) continue;
         V3 result = mk(0, 0, 0);
-        if (np) result = mk(wb.result[slot], wb.result[ns + slot], wb.result[2 * ns + slot]);
-        bool changed = false;
-        const uint32_t bits_lo = (uint32_t)bits, bits_hi = (uint32_t)(bits >> 32);
-        for (uint32_t c0 = 0; c0 < n_pairs; c0 += 64u) {
-            const uint32_t q = c0 + lane;
-            // the sample pair q belongs to: the first lane whose inclusive sum exceeds q
-            uint32_t owner = 0;
+        bool loaded = false, changed = false;
+        for (uint32_t part = 0; part < most; part += 64u) {
+            unsigned long long bits = 0ull;
+            const uint32_t mine_n = cnt > part ? (cnt - part < 64u ? cnt - part : 64u) : 0u;
+            for (uint32_t j = 0; j < mine_n; j++) bits |= (unsigned long long)(wb.sh_vis[first + part + j] != 0) << j;
+            const uint32_t np = (uint32_t)__builtin_popcountll(bits);
+            uint32_t incl = np;
 #pragma unroll
-            for (uint32_t step = 32; step; step >>= 1) {
-                const uint32_t v = __shfl(incl, (int)(owner + step - 1u), 64);
-                if (v <= q) owner += step;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(incl, off, 64);
+                if ((int)lane >= off) incl += v;
             }
-            owner = owner > 63u ? 63u : owner;
-            const uint32_t o_excl = __shfl(excl, (int)owner, 64);
-            const uint32_t o_slot = __shfl(slot, (int)owner, 64);
-            unsigned long long o_bits = ((unsigned long long)__shfl(bits_hi, (int)owner, 64) << 32) | __shfl(bits_lo, (int)owner, 64);
-            V3 c = mk(0, 0, 0);
-            uint32_t valid = 0;
-            if (q < n_pairs) {
-                for (uint32_t r = q - o_excl; r > 0; r--) o_bits &= o_bits - 1ull;      // its (q - o_excl)-th clear pair
-                const int bi = __builtin_ctzll(o_bits);
-                const VertexStore store = slot_store(wb, o_slot);
-                const Vertex cv = store.get<TEX>(a);
-                const Vertex lv = store.get<TEX>(depth + bi);
-                PairGeom g;
-                V3 f_cam, f_light;
-                bool ok = pair_geometry(cv, lv, g);
-                if (ok) {
-                    if (TEX) {
-                        f_cam = (cv.info & kVtxIsLight) ? mk(0, 0, 0) : cv.f;
-                        f_light = lv.f;
-                        ok = !(len2(f_cam) <= 0) && len2(f_light) > 0;
-                    } else {
-                        ok = pair_factors(sc, cv, lv, f_cam, f_light);
-                    }
+            const uint32_t excl = incl - np;
+            const uint32_t n_clear = __shfl(incl, 63, 64);
+            if (n_clear == 0) continue;
+            uint32_t max_np = np;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t v = __shfl_xor(max_np, off, 64); max_np = v > max_np ? v : max_np; }
+            if (np && !loaded) { result = mk(wb.result[slot], wb.result[ns + slot], wb.result[2 * ns + slot]); loaded = true; }
+            const uint32_t bits_lo = (uint32_t)bits, bits_hi = (uint32_t)(bits >> 32);
+            const uint32_t part_first = first + part;
+            for (uint32_t c0 = 0; c0 < n_clear; c0 += 64u) {
+                const uint32_t q = c0 + lane;
+                // the sample clear entry q belongs to: the first lane whose inclusive sum exceeds q
+                uint32_t owner = 0;
+#pragma unroll
+                for (uint32_t step = 32; step; step >>= 1) {
+                    const uint32_t v = __shfl(incl, (int)(owner + step - 1u), 64);
+                    if (v <= q) owner += step;
                 }
-                if (ok) { c = pair_contribution(cv, lv, g, f_cam, f_light); valid = 1u; }
-            }
-            // every sample's lane takes its own pairs of this round, in light-vertex order
-            for (uint32_t j = 0; j < max_np; j++) {
-                const uint32_t mine = excl + j;
-                const uint32_t src = (mine - c0) & 63u;
-                const double cx = __shfl(c.x, (int)src, 64), cy = __shfl(c.y, (int)src, 64), cz = __shfl(c.z, (int)src, 64);
-                const uint32_t v = __shfl(valid, (int)src, 64);
-                if (j < np && mine >= c0 && mine < c0 + 64u && v) { result = add(result, mk(cx, cy, cz)); changed = true; }
+                owner = owner > 63u ? 63u : owner;
+                const uint32_t o_excl = __shfl(excl, (int)owner, 64);
+                const uint32_t o_slot = __shfl(slot, (int)owner, 64);
+                const uint32_t o_first = __shfl(part_first, (int)owner, 64);
+                unsigned long long o_bits = ((unsigned long long)__shfl(bits_hi, (int)owner, 64) << 32) | __shfl(bits_lo, (int)owner, 64);
+                V3 c = mk(0, 0, 0);
+                uint32_t valid = 0;
+                if (q < n_clear) {
+                    for (uint32_t r = q - o_excl; r > 0; r--) o_bits &= o_bits - 1ull;      // its (q - o_excl)-th clear entry
+                    const uint32_t ab = wb.sh_pair[o_first + (uint32_t)__builtin_ctzll(o_bits)];
+                    const VertexStore store = slot_store(wb, o_slot);
+                    const Vertex cv = store.get<TEX>((int)(ab >> 12));
+                    const Vertex lv = store.get<TEX>(depth + (int)(ab & 0xFFFu));
+                    PairGeom g;
+                    V3 f_cam, f_light;
+                    bool ok = pair_geometry(cv, lv, g);
+                    if (ok) {
+                        if (TEX) {
+                            f_cam = (cv.info & kVtxIsLight) ? mk(0, 0, 0) : cv.f;
+                            f_light = lv.f;
+                            ok = !(len2(f_cam) <= 0) && len2(f_light) > 0;
+                        } else {
+                            ok = pair_factors(sc, cv, lv, f_cam, f_light);
+                        }
+                    }
+                    if (ok) { c = pair_contribution(cv, lv, g, f_cam, f_light); valid = 1u; }
+                }
+                // every sample's lane takes its own pairs of this round, in entry order
+                for (uint32_t j = 0; j < max_np; j++) {
+                    const uint32_t mine = excl + j;
+                    const uint32_t src = (mine - c0) & 63u;
+                    const double cx = __shfl(c.x, (int)src, 64), cy = __shfl(c.y, (int)src, 64), cz = __shfl(c.z, (int)src, 64);
+                    const uint32_t v = __shfl(valid, (int)src, 64);
+                    if (j < np && mine >= c0 && mine < c0 + 64u && v) { result = add(result, mk(cx, cy, cz)); changed = true; }
+                }
             }
         }
         if (changed) { wb.result[slot] = result.x; wb.result[ns + slot] = result.y; wb.result[2 * ns + slot] = result.z; }
@@ -1805,7 +1897,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs_in(const double* pairs, uint32
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
         const double* in = pairs + 6 * (uint64_t)k;
         const V3 a = mk(in[0], in[1], in[2]), b = mk(in[3], in[4], in[5]);
-        wb.vis[k] = 0ull;
+        wb.sh_vis[k] = 0;
         const V3 dir = sub(b, a);
         const double dist = len(dir);
         double max_t = -1.0;                    // a negative max_t marks an entry without a ray: "not visible"
@@ -1818,11 +1910,10 @@ __global__ __launch_bounds__(kBlock) void k_pairs_in(const double* pairs, uint32
         wb.shadow[k] = origin.x; wb.shadow[cap + k] = origin.y; wb.shadow[2 * cap + k] = origin.z;
         wb.shadow[3 * cap + k] = dir_unit.x; wb.shadow[4 * cap + k] = dir_unit.y; wb.shadow[5 * cap + k] = dir_unit.z;
         wb.shadow[6 * cap + k] = max_t;
-        wb.shadow[7 * cap + k] = __longlong_as_double((long long)((unsigned long long)k << 16));
     }
 }
 __global__ __launch_bounds__(kBlock) void k_visible_out(WfBuffers wb, uint32_t n, uint8_t* out) {
-    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) out[k] = (uint8_t)(wb.vis[k] & 1ull);
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) out[k] = wb.sh_vis[k];
 }
 
 }  // namespace
@@ -1904,10 +1995,15 @@ static size_t traverse_lds_bytes(const WfLaunchCfg& cfg) {
 hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu) {
     const size_t shm = traverse_lds_bytes(cfg);
     hipError_t e;
-    if (cfg.own_test) {      // k_conn_gen's own-triangle variant stages the reference's tree as well: more than 64 KiB from ~250 triangles on
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conn_gen<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.conn_lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conn_gen<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.conn_lds_bytes);
-        if (e != hipSuccess) return e;
+    if (cfg.conn_lds_bytes > ((size_t)64 << 10)) {      // more than 64 KiB of dynamic LDS has to be asked for
+        const int bytes = (int)cfg.conn_lds_bytes;
+        const void* fns[] = {reinterpret_cast<const void*>(k_connect<false, true, false>), reinterpret_cast<const void*>(k_connect<true, true, false>),
+                             reinterpret_cast<const void*>(k_connect<false, false, true>), reinterpret_cast<const void*>(k_connect<true, false, true>),
+                             reinterpret_cast<const void*>(k_connect<false, false, false>), reinterpret_cast<const void*>(k_connect<true, false, false>)};
+        for (const void* fn : fns) {
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+        }
     }
     if (cfg.instanced) {
         e = prepare_traverse<false, false, false, true>(shm, blocks_per_cu);
@@ -2061,31 +2157,45 @@ hipError_t wf_conn_prepare(const GpuCamera& cam, const WfBuffers& wb, const WfBa
     return hipGetLastError();
 }
 
-hipError_t wf_conn_gen(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
-                       uint32_t* shadow_count, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    dim3 grid(cfg.conn_blocks), block(kStageBlock);
+hipError_t wf_conn_count(const WfBuffers& wb, uint32_t n_slots, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
+    dim3 grid(cfg.stream_blocks), block(kBlock);
+    if (stats) hipLaunchKernelGGL((k_conn_count<true>), grid, block, 0, st, wb, n_slots, stats);
+    else hipLaunchKernelGGL((k_conn_count<false>), grid, block, 0, st, wb, n_slots, stats);
+    return hipGetLastError();
+}
+
+hipError_t wf_conn_plan(const WfBuffers& wb, uint32_t n_slots, const WfLaunchCfg& cfg, hipStream_t st) {
+    hipLaunchKernelGGL(k_conn_plan, dim3(1), dim3(kBlock), 0, st, wb, (n_slots + kConnTile - 1) / kConnTile, cfg.conn_pass_pairs, cfg.conn_passes);
+    return hipGetLastError();
+}
+
+template <bool STATS, bool OWN_TEST, bool TEX>
+static void launch_connect(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, uint32_t n_slots, int pass, uint32_t* shadow_count,
+                           const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
+    hipLaunchKernelGGL((k_connect<STATS, OWN_TEST, TEX>), dim3(cfg.conn_blocks), dim3(64u * cfg.conn_waves), cfg.conn_lds_bytes, st, sc, cam, wb, n_slots,
+                       pass, shadow_count, cfg.conn_rec_budget, cfg.conn_chunk, stats);
+}
+
+hipError_t wf_connect(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, uint32_t n_slots, int pass, uint32_t* shadow_count,
+                      const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
     if (cfg.own_test) {
-        // LDS: the reference's tree, then the triangles with their grazing thresholds and leaf nodes
-        const size_t shm = cfg.conn_lds_bytes;
-        if (stats) hipLaunchKernelGGL((k_conn_gen<true, true>), grid, block, shm, st, sc, cam, wb, a, conn_count, shadow_count, stats);
-        else hipLaunchKernelGGL((k_conn_gen<false, true>), grid, block, shm, st, sc, cam, wb, a, conn_count, shadow_count, stats);
+        if (stats) launch_connect<true, true, false>(sc, cam, wb, n_slots, pass, shadow_count, cfg, stats, st);
+        else launch_connect<false, true, false>(sc, cam, wb, n_slots, pass, shadow_count, cfg, stats, st);
     } else if (cfg.textured) {
-        if (stats) hipLaunchKernelGGL((k_conn_gen<true, false, true>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
-        else hipLaunchKernelGGL((k_conn_gen<false, false, true>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
+        if (stats) launch_connect<true, false, true>(sc, cam, wb, n_slots, pass, shadow_count, cfg, stats, st);
+        else launch_connect<false, false, true>(sc, cam, wb, n_slots, pass, shadow_count, cfg, stats, st);
     } else {
-        if (stats) hipLaunchKernelGGL((k_conn_gen<true, false>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
-        else hipLaunchKernelGGL((k_conn_gen<false, false>), grid, block, 0, st, sc, cam, wb, a, conn_count, shadow_count, stats);
+        if (stats) launch_connect<true, false, false>(sc, cam, wb, n_slots, pass, shadow_count, cfg, stats, st);
+        else launch_connect<false, false, false>(sc, cam, wb, n_slots, pass, shadow_count, cfg, stats, st);
     }
     return hipGetLastError();
 }
 
-hipError_t wf_conn_accum(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, int a, const uint32_t* conn_count,
-                         const WfLaunchCfg& cfg, hipStream_t st) {
-    if (cfg.own_test) hipLaunchKernelGGL((k_conn_accum<true>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
-    else if (wb.vis_words == 1 && cfg.textured) hipLaunchKernelGGL((k_conn_accum_pairs<true>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
-    else if (wb.vis_words == 1) hipLaunchKernelGGL((k_conn_accum_pairs<false>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
-    else if (cfg.textured) hipLaunchKernelGGL((k_conn_accum<false, true>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
-    else hipLaunchKernelGGL((k_conn_accum<false>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, a, conn_count);
+hipError_t wf_conn_add(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, uint32_t n_slots, int pass, const WfLaunchCfg& cfg,
+                       hipStream_t st) {
+    if (cfg.own_test) hipLaunchKernelGGL(k_conn_add_kept, dim3(cfg.stream_blocks), dim3(kBlock), 0, st, wb, n_slots, pass);
+    else if (cfg.textured) hipLaunchKernelGGL((k_conn_add_pairs<true>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, n_slots, pass);
+    else hipLaunchKernelGGL((k_conn_add_pairs<false>), dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, n_slots, pass);
     return hipGetLastError();
 }
 

@@ -542,8 +542,9 @@ def test_device_render_timers(scenes, ctx):
     assert sc.last_kernel_ms() > 0.0
     ms0, n0 = sc.last_stage_ms(0)
     ms1, n1 = sc.last_stage_ms(1)
-    # per batch: depth + (depth - 1) closest-hit launches and depth visibility launches
-    assert n0 > 0 and n0 % (2 * 5 - 1) == 0 and n1 == (n0 // (2 * 5 - 1)) * 5
+    # per batch: depth + (depth - 1) closest-hit launches, and one visibility launch per pass of the connection stage
+    batches = n0 // (2 * 5 - 1)
+    assert n0 > 0 and n0 % (2 * 5 - 1) == 0 and n1 >= batches and n1 % batches == 0
     assert ms0 > 0.0 and ms1 >= 0.0
     assert_bit_equal(fb.cpu().numpy(), want, "device render")
     sc.render_device(cam, fb.data_ptr(), seed=4)
