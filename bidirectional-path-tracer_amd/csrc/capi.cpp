@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/bdpt_amd.h"
@@ -393,7 +394,8 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     // of the connection stage take as many samples at a time as the queue holds for certain)
     const double cap_per_slot = !conn_queue ? 0.0 : (double)d1 * kn.conn_cap_tenths / 10.0;
     // bytes of state per sample slot
-    const size_t per_slot = sizeof(double) * (6 + 3 + 1 + 3) + sizeof(uint32_t) * 5 + (scene->ordered ? 4 : 0) + vslots * rec_doubles * sizeof(double) +
+    // (ray, throughput and stream position twice: by entry of the live queue and of the next one)
+    const size_t per_slot = sizeof(double) * (2 * 6 + 2 * 3 + 1 + 3) + sizeof(uint32_t) * (5 + 2) + (scene->ordered ? 4 : 0) + vslots * rec_doubles * sizeof(double) +
                             (conn_queue ? 8 + 1 : 0) +
                             // the queue: a third more than what a pass may be given (pieces partly lost), a quarter more for
                             // the pieces the waves leave unused at the end (conn_blocks below is limited accordingly)
@@ -481,8 +483,8 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     // carve one workspace per stream
     size_t off = 0;
     auto take = [&off](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
-    const size_t o_ray = take(ns * 6 * 8), o_thr = take(ns * 3 * 8), o_hit = take(ns * 8), o_res = take(ns * 3 * 8);
-    const size_t o_tri = take(ns * 4), o_ctr = take(ns * 4), o_cnt = take(ns * 4);
+    const size_t o_ray = take(ns * 6 * 8), o_ray2 = take(ns * 6 * 8), o_thr = take(ns * 3 * 8), o_thr2 = take(ns * 3 * 8), o_hit = take(ns * 8), o_res = take(ns * 3 * 8);
+    const size_t o_tri = take(ns * 4), o_ctr = take(ns * 4), o_cq1 = take(ns * 4), o_cq2 = take(ns * 4), o_cnt = take(ns * 4);
     const size_t o_q0 = take(ns * 4), o_q1 = take(ns * 4), o_cq = take(scene->ordered ? ns * 4 : 0);
     const uint64_t ns_grouped = (ns + kVtxGroup - 1) / kVtxGroup * kVtxGroup;      // whole groups of slots
     const size_t o_vtx = take(ns_grouped * vslots * rec_doubles * 8), o_sh = take(shadow_cap * 7 * 8), o_shvis = take(shadow_cap);
@@ -537,6 +539,8 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         char* base = ws_base + per_stream * (size_t)s;
         WfBuffers& wb = wbs[s];
         wb.ray = reinterpret_cast<double*>(base + o_ray); wb.thr = reinterpret_cast<double*>(base + o_thr);
+        wb.ray_next = reinterpret_cast<double*>(base + o_ray2); wb.thr_next = reinterpret_cast<double*>(base + o_thr2);
+        wb.ctrq = reinterpret_cast<uint32_t*>(base + o_cq1); wb.ctrq_next = reinterpret_cast<uint32_t*>(base + o_cq2);
         wb.hit = reinterpret_cast<double*>(base + o_hit); wb.result = reinterpret_cast<double*>(base + o_res);
         wb.tmax = nullptr;
         wb.hit_tri = reinterpret_cast<int32_t*>(base + o_tri); wb.ctr = reinterpret_cast<uint32_t*>(base + o_ctr);
@@ -609,41 +613,52 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         b.n_owned = n_owned;
         const uint32_t n_slots = (uint32_t)((int64_t)b.n_pixels * spp);
 
+        // the path state by queue entry: launch k reads the arrays of parity k & 1 and writes those of the other
+        auto step = [&](int k) {
+            WfBuffers w = wb;
+            if (k & 1) { std::swap(w.ray, w.ray_next); std::swap(w.thr, w.thr_next); std::swap(w.ctrq, w.ctrq_next); }
+            return w;
+        };
+        const bool keep_draws = connections || stats_mode != 0;     // (see k_shade)
         HIP_TRY(hipMemsetAsync(C, 0, n_counters * 4, st));
         HIP_TRY(wf_gen_eye(scene->dev, gcam, wb, b, cfg, st));
         int cur = 0;
         // unidirectional estimator: camera.h:255-292, one launch pair per level of the recursion
         for (int k = 0; k < depth && unidirectional; k++) {
+            const WfBuffers w = step(k);
             const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
             const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
             const int nxt = (k == 0) ? 0 : (cur ^ 1);
-            { int rc = timed(0, st, [&] { return wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st, wb.queue[nxt], eye_redo(k)); }); if (rc != BDPT_OK) return rc; }
-            HIP_TRY(wf_redo(scene->dev, wb, cfg, st, wb.queue[nxt], eye_redo(k)));
-            HIP_TRY(wf_shade_unidirectional(scene->dev, gcam, wb, b, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k, k == depth - 1, cfg, stats, st));
+            { int rc = timed(0, st, [&] { return wf_extend(scene->dev, w, c_in, n_slots, eye_cursor(k), cfg, stats, st, wb.queue[nxt], eye_redo(k)); }); if (rc != BDPT_OK) return rc; }
+            HIP_TRY(wf_redo(scene->dev, w, cfg, st, wb.queue[nxt], eye_redo(k)));
+            HIP_TRY(wf_shade_unidirectional(scene->dev, gcam, w, b, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k, k == depth - 1, cfg, stats, st));
             cur = nxt;
         }
         // eye subpath: camera.h:303 -> trace_path(r, depth, ...)
         for (int k = 0; k < depth && !unidirectional; k++) {
+            const WfBuffers w = step(k);
             const uint32_t* q_in = (k == 0) ? nullptr : wb.queue[cur];
             const uint32_t* c_in = (k == 0) ? nullptr : eye_count(k - 1);
             const int nxt = (k == 0) ? 0 : (cur ^ 1);
-            { int rc = timed(0, st, [&] { return cfg.ordered ? wf_walk_ordered(scene->dev, gcam, wb, b, q_in, c_in, n_slots, cfg, st)
-                                                             : wf_extend(scene->dev, wb, q_in, c_in, n_slots, eye_cursor(k), cfg, stats, st, wb.queue[nxt], eye_redo(k)); }); if (rc != BDPT_OK) return rc; }
-            if (!cfg.ordered) HIP_TRY(wf_redo(scene->dev, wb, cfg, st, wb.queue[nxt], eye_redo(k)));
-            HIP_TRY(wf_shade(scene->dev, gcam, wb, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, connections, cfg,
+            { int rc = timed(0, st, [&] { return cfg.ordered ? wf_walk_ordered(scene->dev, gcam, w, b, q_in, c_in, n_slots, cfg, st)
+                                                             : wf_extend(scene->dev, w, c_in, n_slots, eye_cursor(k), cfg, stats, st, wb.queue[nxt], eye_redo(k)); }); if (rc != BDPT_OK) return rc; }
+            if (!cfg.ordered) HIP_TRY(wf_redo(scene->dev, w, cfg, st, wb.queue[nxt], eye_redo(k)));
+            HIP_TRY(wf_shade(scene->dev, gcam, w, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, connections, keep_draws, cfg,
                              stats, st));
             cur = nxt;
         }
         // light subpath: camera.h:313 -> build_light_path -> trace_path(light_ray, depth - 1, ...)
         if (depth > 0 && connections) {
-            HIP_TRY(wf_gen_light(scene->dev, gcam, wb, b, wb.queue[0], light_count(0), cfg, stats, st));
+            // (k_gen_light writes the `_next` arrays: those of parity 1 are the input of launch 0)
+            HIP_TRY(wf_gen_light(scene->dev, gcam, step(1), b, wb.queue[0], light_count(0), cfg, stats, st));
             cur = 0;
             for (int k = 0; k < depth - 1; k++) {
-                { int rc = timed(0, st, [&] { return cfg.ordered ? wf_walk_ordered(scene->dev, gcam, wb, b, wb.queue[cur], light_count(k), 0, cfg, st)
-                                                                 : wf_extend(scene->dev, wb, wb.queue[cur], light_count(k), 0, light_cursor(k), cfg, stats, st, wb.queue[cur ^ 1], light_redo(k)); }); if (rc != BDPT_OK) return rc; }
-                if (!cfg.ordered) HIP_TRY(wf_redo(scene->dev, wb, cfg, st, wb.queue[cur ^ 1], light_redo(k)));
-                HIP_TRY(wf_shade(scene->dev, gcam, wb, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
-                                 light_count(k + 1), k == depth - 2, true, cfg, stats, st));
+                const WfBuffers w = step(k);
+                { int rc = timed(0, st, [&] { return cfg.ordered ? wf_walk_ordered(scene->dev, gcam, w, b, wb.queue[cur], light_count(k), 0, cfg, st)
+                                                                 : wf_extend(scene->dev, w, light_count(k), 0, light_cursor(k), cfg, stats, st, wb.queue[cur ^ 1], light_redo(k)); }); if (rc != BDPT_OK) return rc; }
+                if (!cfg.ordered) HIP_TRY(wf_redo(scene->dev, w, cfg, st, wb.queue[cur ^ 1], light_redo(k)));
+                HIP_TRY(wf_shade(scene->dev, gcam, w, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
+                                 light_count(k + 1), k == depth - 2, true, keep_draws, cfg, stats, st));
                 cur ^= 1;
             }
         }
@@ -775,7 +790,7 @@ int trace_closest_pipeline(bdpt_context* ctx, const bdpt_scene* scene, const dou
         const double* rays = d_rays + 8 * first;
         HIP_TRY(hipMemsetAsync(cursor, 0, 3 * sizeof(uint32_t), stream));
         HIP_TRY(wf_rays_in(rays, m, wb, tmax, ray_len, stream));
-        HIP_TRY(wf_extend(scene->dev, wb, nullptr, nullptr, m, cursor, cfg, nullptr, stream, reinterpret_cast<uint32_t*>(base + o_redo), cursor + 2));
+        HIP_TRY(wf_extend(scene->dev, wb, nullptr, m, cursor, cfg, nullptr, stream, reinterpret_cast<uint32_t*>(base + o_redo), cursor + 2));
         HIP_TRY(wf_redo(scene->dev, wb, cfg, stream, reinterpret_cast<uint32_t*>(base + o_redo), cursor + 2));
         HIP_TRY(wf_hits_out(scene->dev, rays, m, wb, d_hits + 11 * first, stream));
     }

@@ -13,13 +13,23 @@ namespace bdpt {
 
 // Per-batch state, one entry per sample slot (capacity `ns`); slot = s * pixels_in_batch + p, so
 // neighbouring lanes hold the same sample index of neighbouring pixels.
+// The state of a path that is under way travels with its place in the queue, not with its sample slot: entry k of the
+// live queue has its ray, throughput and stream position at index k of these arrays, the traversal writes the hit to
+// index k, and the shading kernel writes the state of a path that goes on to the path's place in the NEXT queue (the
+// `_next` arrays).  Every such access is a contiguous piece of memory per wave; indexed by slot - the live samples
+// thin out bounce by bounce - each was a gather or scatter that kept the texture addresser busy for most of the
+// shading kernels' time.
 struct WfBuffers {
-    double* ray;          // [6][ns]  origin, direction of the ray to trace next
-    double* thr;          // [3][ns]  path throughput
-    double* hit;          // [ns]     t of the last closest hit
+    double* ray;          // [6][ns]  by queue entry: origin, direction of the ray to trace / that was traced
+    double* ray_next;     // [6][ns]  ... of the next queue
+    double* thr;          // [3][ns]  by queue entry: path throughput
+    double* thr_next;
+    uint32_t* ctrq;       // [ns]     by queue entry: random numbers drawn so far by the sample
+    uint32_t* ctrq_next;
+    double* hit;          // [ns]     by queue entry: t of the closest hit
     const double* tmax;   // [ns]     upper end of the interval of a closest-hit ray, or null: +infinity (trace_path, camera.h:336)
-    int32_t* hit_tri;     // [ns]     position of the hit triangle in the leaf-ordered table, or -1
-    uint32_t* ctr;        // [ns]     random numbers drawn so far by the sample
+    int32_t* hit_tri;     // [ns]     by queue entry: position of the hit triangle in the leaf-ordered table, or -1
+    uint32_t* ctr;        // [ns]     by slot: random numbers drawn by the sample when its subpath ended
     double* result;       // [3][ns]  radiance of the sample
     uint32_t* counts;     // [ns]     n_eye | n_light << 12 | flags << 24
     double* vtx;          // [ns / kVtxGroup][2*depth][10][kVtxGroup]  stored (non-delta) path vertices: eye 0.., light depth..
@@ -37,7 +47,7 @@ struct WfBuffers {
                           // tests the far end's own triangle), or null: clear pairs are evaluated again when they are added
     uint32_t* ent_first;  // [ns]     first queue entry of the sample's pairs in the current pass
     uint32_t* ent_count;  // [ns]     number of its entries
-    unsigned long long* tile_pairs;   // [ns / kConnTile + 1]  candidate pairs of each tile of slots, then their running sums
+    unsigned long long* tile_pairs;   // [ns / kConnTile + 1]  candidate pairs of each tile of slots
     uint32_t* pass_bounds;    // [passes + 1]  the tiles of pass p: pass_bounds[p] .. pass_bounds[p + 1]
     uint32_t* counters;   // queue sizes and work-distribution cursors, zeroed once per batch
     const float* ray_len_ptr;  // upper bound of |direction| over the closest-hit rays: *ray_len_ptr, or ray_len when null
@@ -52,6 +62,10 @@ constexpr uint32_t kVtxGroup = 64;
 
 // wb.hit_tri value of a ray whose closest hit the traversal kernel leaves to the walk over the reference's own tree
 constexpr int32_t kHitRedo = -2;
+// A queue entry without a path.  The shading kernels give every path that MAY go on its place in the next queue before
+// they shade it (one atomic per tile of entries); the rare path that then ends after all (a degenerate surface) leaves
+// this in place of its slot, and a direction of zero, which the traversal does not walk.
+constexpr uint32_t kDeadSlot = 0xFFFFFFFFu;
 // scenes with media (k_walk_ordered): wb.hit_tri value kHitMedium0 - k of a ray that ends inside the medium of object k
 constexpr int32_t kHitMedium0 = -3;
 
@@ -110,14 +124,14 @@ hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers&
 // closest-hit traversal of a queue; wf_redo, called next on the same stream, launches k_redo over the rays it left
 // open (two calls so that a caller can time the traversal launch by itself).  redo_list: room for one entry per ray of
 // the launch (the queue the following shading launch will fill is free until then); redo_count: zero when called
-hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
+hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* count_ptr,
                      uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st,
                      uint32_t* redo_list, uint32_t* redo_count);
 hipError_t wf_redo(const SceneDev& sc, const WfBuffers& wb, const WfLaunchCfg& cfg, hipStream_t st, uint32_t* redo_list, uint32_t* redo_count);
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
                     const uint32_t* queue_in, const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
-                    uint32_t* count_out, bool last_bounce, bool store_vertices, const WfLaunchCfg& cfg, unsigned long long* stats,
-                    hipStream_t st);
+                    uint32_t* count_out, bool last_bounce, bool store_vertices, bool keep_draw_counts, const WfLaunchCfg& cfg,
+                    unsigned long long* stats, hipStream_t st);
 // one level of camera::path_trace_color (the unidirectional estimator): records into wb.vtx slot `level`
 hipError_t wf_shade_unidirectional(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const uint32_t* queue_in,
                                    const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out, uint32_t* count_out, int level,

@@ -54,6 +54,31 @@ BDPT_DEV void tile_append(const bool (&flag)[kStagePerThread], const uint32_t (&
     __syncthreads();
 }
 
+// The same, and every flagged entry learns where it went (`at`; unchanged for the others).
+BDPT_DEV void tile_append_at(const bool (&flag)[kStagePerThread], const uint32_t (&value)[kStagePerThread], uint32_t* queue,
+                             uint32_t* count, uint32_t* s_wave, uint32_t* s_base, uint32_t (&at)[kStagePerThread]) {
+    unsigned long long m[kStagePerThread];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < kStagePerThread; j++) { m[j] = __ballot(flag[j]); mine += (uint32_t)__builtin_popcountll(m[j]); }
+    const uint32_t wave = threadIdx.x >> 6;
+    if (lane_id() == 0) s_wave[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < (uint32_t)kStageWaves; w++) { const uint32_t t = s_wave[w]; s_wave[w] = run; run += t; }
+        *s_base = run ? atomicAdd(count, run) : 0u;
+    }
+    __syncthreads();
+    uint32_t next = *s_base + s_wave[wave];
+#pragma unroll
+    for (int j = 0; j < kStagePerThread; j++) {
+        if (flag[j]) { at[j] = next + rank_in_mask(m[j]); queue[at[j]] = value[j]; }
+        next += (uint32_t)__builtin_popcountll(m[j]);
+    }
+    __syncthreads();
+}
+
 BDPT_DEV void flush_wave_counter(unsigned long long* dst, unsigned long long x) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
@@ -106,14 +131,14 @@ BDPT_DEV uint32_t slot_vertex_info(const WfBuffers& wb, uint32_t slot, int rec) 
 __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb, WfBatch b) {
     const uint32_t spp = (uint32_t)(cam.sqrt_spp * cam.sqrt_spp);
     const uint64_t n = (uint64_t)b.pixels_stride * spp;
+    // (the first queue is the slots themselves: entry k = slot k)
     for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * kBlock) {
         int i, j, s;
-        wb.hit_tri[slot] = -1;
         wb.counts[slot] = 0;
         wb.result[slot] = 0.0; wb.result[wb.ns + slot] = 0.0; wb.result[2 * wb.ns + slot] = 0.0;
         if (!slot_to_sample(cam, b, (uint32_t)slot, i, j, s)) {
             wb.ctr[slot] = 0;
-            // inactive slots still get a harmless ray (they are traced in the first bounce like all others)
+            // a slot without a sample: a direction of zero, which the traversal does not walk
             wb.ray[slot] = 0; wb.ray[wb.ns + slot] = 0; wb.ray[2 * wb.ns + slot] = 0;
             wb.ray[3 * wb.ns + slot] = 0; wb.ray[4 * wb.ns + slot] = 0; wb.ray[5 * wb.ns + slot] = 0;
             continue;
@@ -127,7 +152,8 @@ __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb,
         wb.ray[slot] = o.x; wb.ray[wb.ns + slot] = o.y; wb.ray[2 * wb.ns + slot] = o.z;
         wb.ray[3 * wb.ns + slot] = d.x; wb.ray[4 * wb.ns + slot] = d.y; wb.ray[5 * wb.ns + slot] = d.z;
         wb.thr[slot] = 1.0; wb.thr[wb.ns + slot] = 1.0; wb.thr[2 * wb.ns + slot] = 1.0;
-        wb.ctr[slot] = rng.counter;
+        wb.ctrq[slot] = rng.counter;
+        wb.ctr[slot] = rng.counter;       // (what stands when no bounce follows: max_depth 0)
     }
 }
 
@@ -489,7 +515,7 @@ BDPT_DEV RefTree stage_ref_tree(const SceneDev& sc, unsigned char* dst) {
 // sees it (the reference's translate::hit / rotate_y::hit in front of triangle::hit), everything else is unchanged -
 // the ray parameter t is the same number in both coordinate systems.
 template <bool SHADOW, bool STATS, bool INSTANCED, class Mem, class Ref>
-BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, uint32_t count,
+BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc, const WfBuffers& wb, uint32_t count,
                              uint32_t* cursor, unsigned long long* stats, const int kRefillThreshold, const uint32_t kChunk,
                              const int kLeafThreshold, const int kLeafInner, const double coord_bound, double* lds_stack, const int kLdsStack,
                              const uint32_t first_base, uint32_t* redo_list, uint32_t* redo_count) {
@@ -560,13 +586,17 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                         tmax0 = wb.shadow[6 * cap + k];
                         entry = k;
                     } else {
-                        slot = queue ? queue[k] : k;
+                        slot = k;               // (the ray's place in the queue: its state lives there)
                         const uint64_t ns = wb.ns;
-                        o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
-                        d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
-                        tmax0 = wb.tmax ? wb.tmax[slot] : kInf;
+                        o = mk(wb.ray[k], wb.ray[ns + k], wb.ray[2 * ns + k]);
+                        d = mk(wb.ray[3 * ns + k], wb.ray[4 * ns + k], wb.ray[5 * ns + k]);
+                        tmax0 = wb.tmax ? wb.tmax[k] : kInf;
+                        // a direction of zero: an entry without a path (kDeadSlot), or a query no triangle can accept (its
+                        // determinant is zero for every triangle, triangle.h:49-50)
+                        // (... nor does an interval that ends below zero or is not a number hold anything)
+                        if ((d.x == 0.0 && d.y == 0.0 && d.z == 0.0) || !(tmax0 >= 0.0)) { wb.hit_tri[k] = -1; tmax0 = -1.0; }
                     }
-                    if (!SHADOW || tmax0 >= 0.0) {              // a negative max_t marks an unused queue entry
+                    if (tmax0 >= 0.0) {              // a negative max_t marks an unused queue entry
                         rf = ray_f32(o, d, bound_f32);
                         if (INSTANCED) cached_ob = -1;
                         closest = tmax0;
@@ -765,7 +795,7 @@ BDPT_DEV void stage_tree(const NodeT* nodes, uint32_t n_nodes, const GpuTri* tri
 }
 
 template <bool SHADOW, bool STATS, bool LDS_SCENE, bool INSTANCED = false>
-__global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, const uint32_t* queue,
+__global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb,
                                                     const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                     unsigned long long* stats, int refill_threshold, uint32_t chunk,
                                                     uint32_t top_nodes, int leaf_threshold, int leaf_inner, uint32_t scene_lds_bytes,
@@ -802,11 +832,11 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
             // (the copy of the reference's tree lies behind the stack part; only visibility rays consult it)
             if (SHADOW) {
                 const RefTree ref = stage_ref_tree(sc, smem + scene_lds_bytes + (size_t)(lds_stack + 1) * kBlock * sizeof(double));
-                traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
+                traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
                 return;
             }
             const GlobalRefTree ref;
-            traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
+            traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
         } else {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
@@ -814,11 +844,11 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb, 
             TopLdsMem<GpuQuadNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
             if (INSTANCED) {
                 const InstancedRefTree ref;
-                traverse_queue<SHADOW, STATS, true>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
+                traverse_queue<SHADOW, STATS, true>(mem, ref, sc, wb, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
                 return;
             }
             const GlobalRefTree ref;
-            traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, queue, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
+            traverse_queue<SHADOW, STATS, false>(mem, ref, sc, wb, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
         }
     }
 }
@@ -876,7 +906,7 @@ __global__ __launch_bounds__(kBlock) void k_redo(SceneDev sc, WfBuffers wb, cons
     const uint32_t n_waves = gridDim.x * (kBlock >> 6);
     const uint32_t wave = blockIdx.x * (kBlock >> 6) + (threadIdx.x >> 6);
     for (uint64_t k = wave + (uint64_t)n_waves * lane_id(); k < count; k += (uint64_t)n_waves * 64u) {
-        const uint32_t slot = list[k];
+        const uint32_t slot = list[k];              // (the ray's place in the live queue)
         const V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
         const V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
         const double tmax = wb.tmax ? wb.tmax[slot] : kInf;
@@ -926,20 +956,20 @@ __global__ __launch_bounds__(kBlock) void k_walk_ordered(SceneDev sc, GpuCamera 
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
         const uint32_t slot = queue ? queue[k] : k;
         int pi, pj, ps;
-        if (!slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
-        const V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
-        const V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
-        const uint32_t ctr0 = wb.ctr[slot];
+        if (slot == kDeadSlot || !slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
+        const V3 o = mk(wb.ray[k], wb.ray[ns + k], wb.ray[2 * ns + k]);
+        const V3 d = mk(wb.ray[3 * ns + k], wb.ray[4 * ns + k], wb.ray[5 * ns + k]);
+        const uint32_t ctr0 = wb.ctrq[k];
         Rng rng = slot_rng(cam, b, slot, ctr0);
         Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         CxHit h;
         int32_t code = -1;
         if (cx_walk<kStatsOff>(sc, o, d, 0.001, kInf, h, c, rng)) {
             code = (h.tri < 0) ? kHitMedium0 - h.obj : (int32_t)((h.obj >= 0 ? sc.obj_pos0[h.obj] : 0u) + sc.tri_pos[h.tri]);
-            wb.hit[slot] = h.t;
+            wb.hit[k] = h.t;
         }
-        wb.hit_tri[slot] = code;
-        if (rng.counter != ctr0) wb.ctr[slot] = rng.counter;
+        wb.hit_tri[k] = code;
+        if (rng.counter != ctr0) wb.ctrq[k] = rng.counter;
     }
 }
 
@@ -1049,10 +1079,17 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_ordered(SceneDev sc, GpuCa
 // triangle test (the traversal kernels keep no u, v).
 // MEDIA (with TEX): the hits come from k_walk_ordered; a negative code <= kHitMedium0 stands for a point inside the
 // medium -(code - kHitMedium0) (constant_medium.h:45-50: normal (1, 0, 0), front face, the medium's phase function).
+// Queue order.  A path's ray, throughput and stream position are read from its entry k of the live queue and, when it goes
+// on, written to its entry of the next queue, so both are contiguous accesses.  For that the entry of the next queue has
+// to be known before the path is shaded: every hit on a surface that scatters (anything but an emitter) gets one, a tile
+// of entries at a time with one atomic; whether such a path really goes on is then all but certain (a lambertian sample
+// with a pdf of zero or a NaN is the exception), and the exception leaves kDeadSlot and a direction of zero behind.
+// keep_draws: a path that ends leaves its number of draws with its slot (the light subpath starts there, the connection
+// stage of a scene with media goes on from there, the counting modes add them up).
 template <bool EYE, bool STATS, bool LAMBERT, bool INSTANCED = false, bool TEX = false, bool MEDIA = false>
 __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
                                                   const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
-                                                  uint32_t* count_out, int last_bounce, int store_vertices, unsigned long long* stats) {
+                                                  uint32_t* count_out, int last_bounce, int store_vertices, int keep_draws, unsigned long long* stats) {
     __shared__ uint32_t s_wave[kStageWaves];
     __shared__ uint32_t s_base;
     const uint32_t count = count_in_ptr ? *count_in_ptr : count_in_imm;
@@ -1061,33 +1098,51 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
     uint32_t n_stored = 0;
     // whole workgroups iterate together so that the append sees every thread
     for (uint32_t tile = blockIdx.x * kStageTile; tile < count; tile += gridDim.x * kStageTile) {
-        uint32_t cont_mask = 0;          // bit j: entry j goes on (one register instead of four while the entries are shaded)
-        uint32_t slots[kStagePerThread];
+        uint32_t slots[kStagePerThread], at[kStagePerThread];
+        bool may_go_on[kStagePerThread];
+#pragma unroll
+        for (int j = 0; j < kStagePerThread; j++) {
+            const uint32_t k = tile + (uint32_t)j * kStageBlock + threadIdx.x;
+            slots[j] = kDeadSlot;
+            at[j] = 0;
+            may_go_on[j] = false;
+            if (k >= count) continue;
+            const uint32_t slot = queue_in ? queue_in[k] : k;
+            int pi, pj, ps;
+            if (slot == kDeadSlot || !slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
+            slots[j] = slot;
+            if (last_bounce) continue;
+            const int32_t pos = wb.hit_tri[k];
+            if (MEDIA && pos <= kHitMedium0) may_go_on[j] = true;                   // the phase function of a medium always scatters
+            else if (pos >= 0) may_go_on[j] = (sc.shade[pos].mat >> 30) != 3u;      // every material but an emitter may
+        }
+        tile_append_at(may_go_on, slots, queue_out, count_out, s_wave, &s_base, at);
 #pragma unroll 1
         for (int j = 0; j < kStagePerThread; j++) {
             const uint32_t k = tile + (uint32_t)j * kStageBlock + threadIdx.x;
-            slots[j] = 0;
-            if (k >= count) continue;
-            const uint32_t slot = queue_in ? queue_in[k] : k;
-            slots[j] = slot;
-            int pi, pj, ps;
-            if (!slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
-            int32_t pos = wb.hit_tri[slot];           // position of the hit triangle in the reference's leaf order
+            const uint32_t slot = slots[j];
+            if (slot == kDeadSlot) continue;
+            int32_t pos = wb.hit_tri[k];           // position of the hit triangle in the reference's leaf order
             const bool medium = MEDIA && pos <= kHitMedium0;
             double t_hit = 0.0;
-            if (pos >= 0 || medium) t_hit = wb.hit[slot];        // (k_redo has resolved the rays the traversal kernel left open)
-            V3 T = mk(wb.thr[slot], wb.thr[ns + slot], wb.thr[2 * ns + slot]);
+            if (pos >= 0 || medium) t_hit = wb.hit[k];        // (k_redo has resolved the rays the traversal kernel left open)
+            V3 T = mk(wb.thr[k], wb.thr[ns + k], wb.thr[2 * ns + k]);
+            const uint32_t ctr0 = wb.ctrq[k];
             if (pos < 0 && !medium) {
                 if (EYE) {   // camera.h:337-338: background_contrib (0) += throughput * background
                     V3 bg = add(mk(0, 0, 0), mulv(T, ld3(cam.background)));
                     wb.result[slot] = bg.x; wb.result[ns + slot] = bg.y; wb.result[2 * ns + slot] = bg.z;
                 }
+                if (keep_draws) wb.ctr[slot] = ctr0;
                 continue;
             }
-            V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
-            V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
-            const uint32_t ctr0 = wb.ctr[slot];
-            Rng rng = slot_rng(cam, b, slot, ctr0);
+            V3 o = mk(wb.ray[k], wb.ray[ns + k], wb.ray[2 * ns + k]);
+            V3 d = mk(wb.ray[3 * ns + k], wb.ray[4 * ns + k], wb.ray[5 * ns + k]);
+            int pi, pj, ps;
+            slot_to_sample(cam, b, slot, pi, pj, ps);
+            Rng rng;
+            rng.key = stream_key(b.seed, (uint64_t)pj * (uint64_t)cam.width + (uint64_t)pi, (uint64_t)ps);
+            rng.counter = ctr0;
             Bounce bo;
             if (MEDIA && medium) {
                 const int32_t mat_id = sc.objs[kHitMedium0 - pos].phase_material;
@@ -1131,8 +1186,6 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             } else {
                 shade_bounce_at<EYE, LAMBERT>(sc, (uint32_t)pos, o, d, t_hit, T, rng, bo);
             }
-            // state that a bounce leaves as it was is not written again (a specular bounce keeps no vertex, a
-            // dielectric one leaves the throughput alone: x * 1.0 is x)
             if (bo.keep && store_vertices) {       // (no vertex store in a scene that cannot form a connection)
                 uint32_t cnt = wb.counts[slot];
                 const uint32_t ne = cnt & 0xFFFu, nl = (cnt >> 12) & 0xFFFu;
@@ -1146,23 +1199,20 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
                 V3 e = add(mk(0, 0, 0), bo.emitted_term);
                 wb.result[slot] = e.x; wb.result[ns + slot] = e.y; wb.result[2 * ns + slot] = e.z;
             }
-            if (rng.counter != ctr0) wb.ctr[slot] = rng.counter;
-            if (bo.cont && !last_bounce) {
-                cont_mask |= 1u << j;
-                wb.ray[slot] = bo.o.x; wb.ray[ns + slot] = bo.o.y; wb.ray[2 * ns + slot] = bo.o.z;
-                wb.ray[3 * ns + slot] = bo.d.x; wb.ray[4 * ns + slot] = bo.d.y; wb.ray[5 * ns + slot] = bo.d.z;
-                const bool same_bits = __double_as_longlong(bo.T.x) == __double_as_longlong(T.x) &&
-                                       __double_as_longlong(bo.T.y) == __double_as_longlong(T.y) &&
-                                       __double_as_longlong(bo.T.z) == __double_as_longlong(T.z);
-                if (!same_bits) {
-                    wb.thr[slot] = bo.T.x; wb.thr[ns + slot] = bo.T.y; wb.thr[2 * ns + slot] = bo.T.z;
+            if (may_go_on[j]) {
+                const uint32_t to = at[j];
+                if (bo.cont) {
+                    wb.ray_next[to] = bo.o.x; wb.ray_next[ns + to] = bo.o.y; wb.ray_next[2 * ns + to] = bo.o.z;
+                    wb.ray_next[3 * ns + to] = bo.d.x; wb.ray_next[4 * ns + to] = bo.d.y; wb.ray_next[5 * ns + to] = bo.d.z;
+                    wb.thr_next[to] = bo.T.x; wb.thr_next[ns + to] = bo.T.y; wb.thr_next[2 * ns + to] = bo.T.z;
+                    wb.ctrq_next[to] = rng.counter;
+                } else {               // it ends after all: nobody's entry
+                    queue_out[to] = kDeadSlot;
+                    wb.ray_next[3 * ns + to] = 0.0; wb.ray_next[4 * ns + to] = 0.0; wb.ray_next[5 * ns + to] = 0.0;
                 }
             }
+            if (keep_draws && !(may_go_on[j] && bo.cont)) wb.ctr[slot] = rng.counter;
         }
-        bool cont[kStagePerThread];
-#pragma unroll
-        for (int j = 0; j < kStagePerThread; j++) cont[j] = (cont_mask >> j) & 1u;
-        tile_append(cont, slots, queue_out, count_out, s_wave, &s_base);
     }
     if (STATS) flush_wave_counter(&stats[10], n_stored);
 }
@@ -1180,27 +1230,38 @@ __global__ __launch_bounds__(kStageBlock) void k_shade_unidirectional(SceneDev s
     const uint64_t ns = wb.ns;
     unsigned long long draws = 0, samples = 0;
     for (uint32_t tile = blockIdx.x * kStageTile; tile < count; tile += gridDim.x * kStageTile) {
-        bool cont[kStagePerThread];
-        uint32_t slots[kStagePerThread];
+        // (queue order, as in k_shade: every hit may go on and gets its entry of the next queue before it is shaded)
+        bool may_go_on[kStagePerThread];
+        uint32_t slots[kStagePerThread], at[kStagePerThread];
+#pragma unroll
+        for (int j = 0; j < kStagePerThread; j++) {
+            const uint32_t k = tile + (uint32_t)j * kStageBlock + threadIdx.x;
+            slots[j] = kDeadSlot;
+            at[j] = 0;
+            may_go_on[j] = false;
+            if (k >= count) continue;
+            const uint32_t slot = queue_in ? queue_in[k] : k;
+            int pi, pj, ps;
+            if (slot == kDeadSlot || !slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
+            slots[j] = slot;
+            may_go_on[j] = !last_level && wb.hit_tri[k] >= 0;
+        }
+        tile_append_at(may_go_on, slots, queue_out, count_out, s_wave, &s_base, at);
 #pragma unroll 1
         for (int j = 0; j < kStagePerThread; j++) {
             const uint32_t k = tile + (uint32_t)j * kStageBlock + threadIdx.x;
-            slots[j] = 0;
-            cont[j] = false;
-            if (k >= count) continue;
-            const uint32_t slot = queue_in ? queue_in[k] : k;
-            slots[j] = slot;
-            int pi, pj, ps;
-            if (!slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
-            const V3 o = mk(wb.ray[slot], wb.ray[ns + slot], wb.ray[2 * ns + slot]);
-            const V3 d = mk(wb.ray[3 * ns + slot], wb.ray[4 * ns + slot], wb.ray[5 * ns + slot]);
-            const int32_t pos = wb.hit_tri[slot];
+            const uint32_t slot = slots[j];
+            if (slot == kDeadSlot) continue;
+            bool goes_on = false;
+            const V3 o = mk(wb.ray[k], wb.ray[ns + k], wb.ray[2 * ns + k]);
+            const V3 d = mk(wb.ray[3 * ns + k], wb.ray[4 * ns + k], wb.ray[5 * ns + k]);
+            const int32_t pos = wb.hit_tri[k];
             HitLite h;
             h.tri = pos < 0 ? -1 : sc.stris[pos].pad; h.t = 0; h.u = 0; h.v = 0;
-            if (pos >= 0) h.t = wb.hit[slot];
+            if (pos >= 0) h.t = wb.hit[k];
             V3 value = mk(0, 0, 0);           // what the innermost level returns
             int n_records = level;
-            Rng rng = slot_rng(cam, b, slot, wb.ctr[slot]);
+            Rng rng = slot_rng(cam, b, slot, wb.ctrq[k]);
             if (h.tri < 0) {
                 value = ld3(cam.background);                                    // camera.h:264-265
             } else {
@@ -1213,21 +1274,26 @@ __global__ __launch_bounds__(kStageBlock) void k_shade_unidirectional(SceneDev s
                     slot_store(wb, slot).put(level, ub.rec);
                     n_records = level + 1;
                     if (!last_level) {
-                        cont[j] = true;
-                        wb.ray[slot] = ub.o.x; wb.ray[ns + slot] = ub.o.y; wb.ray[2 * ns + slot] = ub.o.z;
-                        wb.ray[3 * ns + slot] = ub.d.x; wb.ray[4 * ns + slot] = ub.d.y; wb.ray[5 * ns + slot] = ub.d.z;
-                        wb.ctr[slot] = rng.counter;
+                        goes_on = true;
+                        const uint32_t to = at[j];
+                        wb.ray_next[to] = ub.o.x; wb.ray_next[ns + to] = ub.o.y; wb.ray_next[2 * ns + to] = ub.o.z;
+                        wb.ray_next[3 * ns + to] = ub.d.x; wb.ray_next[4 * ns + to] = ub.d.y; wb.ray_next[5 * ns + to] = ub.d.z;
+                        wb.ctrq_next[to] = rng.counter;
                     }
                     // (at the last level the next call has no depth left and returns zero, camera.h:258-259)
                 }
             }
-            if (!cont[j]) {
+            if (!goes_on) {
+                if (may_go_on[j]) {           // the recursion ends at this hit after all: nobody's entry
+                    const uint32_t to = at[j];
+                    queue_out[to] = kDeadSlot;
+                    wb.ray_next[3 * ns + to] = 0.0; wb.ray_next[4 * ns + to] = 0.0; wb.ray_next[5 * ns + to] = 0.0;
+                }
                 for (int q = n_records - 1; q >= 0; q--) value = unidirectional_fold(slot_store(wb, slot).get(q), value);
                 wb.result[slot] = value.x; wb.result[ns + slot] = value.y; wb.result[2 * ns + slot] = value.z;
                 if (STATS) { draws += rng.counter; samples++; }
             }
         }
-        tile_append(cont, slots, queue_out, count_out, s_wave, &s_base);
     }
     if (STATS) { flush_wave_counter(&stats[8], draws); flush_wave_counter(&stats[9], samples); }
 }
@@ -1249,15 +1315,25 @@ __global__ __launch_bounds__(kStageBlock) void k_gen_light(SceneDev sc, GpuCamer
     __shared__ uint32_t s_base;
     uint32_t n_stored = 0;
     for (uint32_t tile = blockIdx.x * kStageTile; tile < n; tile += gridDim.x * kStageTile) {
-        bool cont[kStagePerThread];
-        uint32_t slots[kStagePerThread];
-#pragma unroll 1
+        // (queue order, as in k_shade: every sample that gets a light subpath also gets an entry of the first light queue
+        // before its emitter is sampled; the rare one without a first ray leaves the entry to nobody)
+        bool may_go_on[kStagePerThread];
+        uint32_t slots[kStagePerThread], at[kStagePerThread];
+#pragma unroll
         for (int j = 0; j < kStagePerThread; j++) {
             const uint32_t slot = tile + (uint32_t)j * kStageBlock + threadIdx.x;
-            cont[j] = false;
             slots[j] = slot;
+            at[j] = 0;
+            int pi, pj, ps;
+            may_go_on[j] = slot < n && slot_to_sample(cam, b, slot, pi, pj, ps) && (wb.counts[slot] & kCntEyeConnectable) && depth - 1 > 0;
+        }
+        tile_append_at(may_go_on, slots, queue_out, count_out, s_wave, &s_base, at);
+#pragma unroll 1
+        for (int j = 0; j < kStagePerThread; j++) {
+            const uint32_t slot = slots[j];
             int pi, pj, ps;
             if (slot >= n || !slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
+            bool goes_on = false;
             // A light subpath only acts through its connections (camera.h:316-320), and a pair contributes zero
             // when the eye vertex is delta (camera.h:441) or on an emitter (zero BSDF, material.h:35-37): without
             // a connectable eye vertex nothing of the light subpath is sampled, traced or stored.  Its random
@@ -1271,19 +1347,26 @@ __global__ __launch_bounds__(kStageBlock) void k_gen_light(SceneDev sc, GpuCamer
             if (TEX) sample_emitter(sc, depth, rng, em, TexturedEmitterColour{sc});
             else sample_emitter(sc, depth, rng, em);
             wb.ctr[slot] = rng.counter;
-            if (!em.valid) continue;
-            if (sc.objs) em.ev.tri = sc.tri_pos[em.ev.tri];      // (an emitter is a triangle of the world's list: its entry of `stris`)
-            slot_store(wb, slot).put<TEX>(depth, em.ev);
-            if (STATS) n_stored++;
-            wb.counts[slot] = cnt | (1u << 12);
-            if (em.has_ray && depth - 1 > 0) {
-                cont[j] = true;
-                wb.ray[slot] = em.o.x; wb.ray[ns + slot] = em.o.y; wb.ray[2 * ns + slot] = em.o.z;
-                wb.ray[3 * ns + slot] = em.d.x; wb.ray[4 * ns + slot] = em.d.y; wb.ray[5 * ns + slot] = em.d.z;
-                wb.thr[slot] = em.T.x; wb.thr[ns + slot] = em.T.y; wb.thr[2 * ns + slot] = em.T.z;
+            if (em.valid) {
+                if (sc.objs) em.ev.tri = sc.tri_pos[em.ev.tri];      // (an emitter is a triangle of the world's list: its entry of `stris`)
+                slot_store(wb, slot).put<TEX>(depth, em.ev);
+                if (STATS) n_stored++;
+                wb.counts[slot] = cnt | (1u << 12);
+                if (em.has_ray && may_go_on[j]) {
+                    goes_on = true;
+                    const uint32_t to = at[j];
+                    wb.ray_next[to] = em.o.x; wb.ray_next[ns + to] = em.o.y; wb.ray_next[2 * ns + to] = em.o.z;
+                    wb.ray_next[3 * ns + to] = em.d.x; wb.ray_next[4 * ns + to] = em.d.y; wb.ray_next[5 * ns + to] = em.d.z;
+                    wb.thr_next[to] = em.T.x; wb.thr_next[ns + to] = em.T.y; wb.thr_next[2 * ns + to] = em.T.z;
+                    wb.ctrq_next[to] = rng.counter;
+                }
+            }
+            if (may_go_on[j] && !goes_on) {
+                const uint32_t to = at[j];
+                queue_out[to] = kDeadSlot;
+                wb.ray_next[3 * ns + to] = 0.0; wb.ray_next[4 * ns + to] = 0.0; wb.ray_next[5 * ns + to] = 0.0;
             }
         }
-        tile_append(cont, slots, queue_out, count_out, s_wave, &s_base);
     }
     if (STATS) flush_wave_counter(&stats[10], n_stored);
 }
@@ -1345,48 +1428,61 @@ __global__ __launch_bounds__(kBlock) void k_conn_count(WfBuffers wb, uint32_t n_
 }
 
 // The passes of the connection stage: the tiles are dealt out in order, as many to a pass as the shadow queue holds for
-// certain (`pass_pairs` candidate pairs; one tile never has more).  One workgroup: running sums of the tile counts, then
-// the first tile of every pass by bisection.  Tiles beyond the last pass with work make empty passes.
-__global__ __launch_bounds__(kBlock) void k_conn_plan(WfBuffers wb, uint32_t n_tiles, unsigned long long pass_pairs, uint32_t n_passes) {
-    __shared__ unsigned long long s_sum[kBlock];
-    const uint32_t per = (n_tiles + kBlock - 1) / kBlock;
-    const uint32_t lo = threadIdx.x * per < n_tiles ? threadIdx.x * per : n_tiles;
-    const uint32_t hi = lo + per < n_tiles ? lo + per : n_tiles;
-    unsigned long long mine = 0;
-    for (uint32_t t = lo; t < hi; t++) mine += wb.tile_pairs[t];
-    s_sum[threadIdx.x] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int k = 0; k < kBlock; k++) { const unsigned long long v = s_sum[k]; s_sum[k] = run; run += v; }
-    }
-    __syncthreads();
-    unsigned long long run = s_sum[threadIdx.x];
-    for (uint32_t t = lo; t < hi; t++) { run += wb.tile_pairs[t]; wb.tile_pairs[t] = run; }       // inclusive running sums
-    __threadfence_block();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const volatile unsigned long long* sums = wb.tile_pairs;
-        uint32_t start = 0;
-        wb.pass_bounds[0] = 0;
-        for (uint32_t p = 0; p < n_passes; p++) {
-            uint32_t end = n_tiles;
-            if (start < n_tiles) {
-                const unsigned long long before = start ? sums[start - 1] : 0ull;
-                if (sums[n_tiles - 1] - before > pass_pairs) {
-                    // the largest `end` with sums[end - 1] - before <= pass_pairs (at least one tile: a tile always fits)
-                    uint32_t a = start + 1, b = n_tiles;          // the answer lies in [a, b)
-                    while (a + 1 < b) {
-                        const uint32_t mid = a + (b - a) / 2;
-                        if (sums[mid - 1] - before <= pass_pairs) a = mid; else b = mid;
+// certain (`pass_pairs` candidate pairs; one tile never has more).  One workgroup walks over the tile counts, 8192 at a
+// time (eight coalesced loads in flight per thread); a pass ends in front of the first tile that no longer fits, which
+// thread 0 looks for only in a stretch whose total says that it holds one.  Passes beyond the last tile are empty.
+constexpr int kPlanBlock = 1024;
+constexpr int kPlanPerThread = 8;
+__global__ __launch_bounds__(kPlanBlock) void k_conn_plan(WfBuffers wb, uint32_t n_tiles, unsigned long long pass_pairs, uint32_t n_passes) {
+    __shared__ unsigned long long s_wave[kPlanBlock / 64];
+    __shared__ unsigned long long s_vals[kPlanBlock];
+    __shared__ int s_search;
+    // (thread 0 only)
+    unsigned long long running = 0, base = 0;
+    uint32_t next_pass = 1;                   // pass_bounds[next_pass] is the next end to be written
+    if (threadIdx.x == 0) wb.pass_bounds[0] = 0;
+    for (uint32_t blk = 0; blk < n_tiles; blk += kPlanBlock * kPlanPerThread) {
+        unsigned long long v[kPlanPerThread];
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int j = 0; j < kPlanPerThread; j++) {
+            const uint32_t t = blk + (uint32_t)j * kPlanBlock + threadIdx.x;
+            v[j] = t < n_tiles ? wb.tile_pairs[t] : 0ull;
+            sum += v[j];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+        if (lane_id() == 0) s_wave[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long tot = 0;
+            for (int w = 0; w < kPlanBlock / 64; w++) tot += s_wave[w];
+            s_search = (running + tot - base > pass_pairs) ? 1 : 0;
+            if (!s_search) running += tot;
+        }
+        __syncthreads();
+        if (s_search) {                           // (rare: once per pass) a pass ends inside this stretch
+#pragma unroll 1
+            for (int j = 0; j < kPlanPerThread; j++) {
+                s_vals[threadIdx.x] = v[j];
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    for (int i = 0; i < kPlanBlock; i++) {
+                        const unsigned long long r = running + s_vals[i];
+                        if (r - base > pass_pairs) {          // tile blk + j * kPlanBlock + i opens the next pass
+                            if (next_pass <= n_passes) wb.pass_bounds[next_pass] = blk + (uint32_t)j * kPlanBlock + (uint32_t)i;
+                            next_pass++;
+                            base = running;
+                        }
+                        running = r;
                     }
-                    end = a;
                 }
+                __syncthreads();
             }
-            wb.pass_bounds[p + 1] = end;
-            start = end;
         }
     }
+    if (threadIdx.x == 0)
+        for (uint32_t p = next_pass; p <= n_passes; p++) wb.pass_bounds[p] = n_tiles;
 }
 
 // What a connection needs of the materials (camera.h:458-469), worked out once per workgroup into LDS instead of once
@@ -2031,35 +2127,35 @@ hipError_t wf_gen_eye(const SceneDev& sc, const GpuCamera& cam, const WfBuffers&
 }
 
 template <bool SHADOW, bool STATS, bool LDS_SCENE, bool INSTANCED = false>
-static void launch_traverse_as(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
+static void launch_traverse_as(const SceneDev& sc, const WfBuffers& wb, const uint32_t* count_ptr,
                                uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
                                hipStream_t st, uint32_t* redo_list, uint32_t* redo_count) {
     hipLaunchKernelGGL((k_traverse<SHADOW, STATS, LDS_SCENE, INSTANCED>), dim3(cfg.persistent_blocks), dim3(kBlock), traverse_lds_bytes(cfg), st,
-                       sc, wb, queue, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.top_nodes,
+                       sc, wb, count_ptr, count_imm, cursor, stats, cfg.refill_threshold, cfg.chunk, cfg.top_nodes,
                        cfg.leaf_threshold, cfg.leaf_inner, (uint32_t)scene_lds_bytes(cfg), cfg.lds_stack, redo_list, redo_count);
 }
 
 template <bool SHADOW>
-static hipError_t launch_traverse(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
+static hipError_t launch_traverse(const SceneDev& sc, const WfBuffers& wb, const uint32_t* count_ptr,
                                   uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
                                   hipStream_t st, uint32_t* redo_list = nullptr, uint32_t* redo_count = nullptr) {
     if (cfg.instanced) {
-        if (stats) launch_traverse_as<SHADOW, true, false, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
-        else launch_traverse_as<SHADOW, false, false, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+        if (stats) launch_traverse_as<SHADOW, true, false, true>(sc, wb, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+        else launch_traverse_as<SHADOW, false, false, true>(sc, wb, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
     } else if (stats) {
-        if (cfg.lds_scene) launch_traverse_as<SHADOW, true, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
-        else launch_traverse_as<SHADOW, true, false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+        if (cfg.lds_scene) launch_traverse_as<SHADOW, true, true>(sc, wb, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+        else launch_traverse_as<SHADOW, true, false>(sc, wb, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
     } else {
-        if (cfg.lds_scene) launch_traverse_as<SHADOW, false, true>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
-        else launch_traverse_as<SHADOW, false, false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+        if (cfg.lds_scene) launch_traverse_as<SHADOW, false, true>(sc, wb, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+        else launch_traverse_as<SHADOW, false, false>(sc, wb, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
     }
     return hipGetLastError();
 }
 
-hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* queue, const uint32_t* count_ptr,
+hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* count_ptr,
                      uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st,
                      uint32_t* redo_list, uint32_t* redo_count) {
-    return launch_traverse<false>(sc, wb, queue, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+    return launch_traverse<false>(sc, wb, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
 }
 
 hipError_t wf_redo(const SceneDev& sc, const WfBuffers& wb, const WfLaunchCfg& cfg, hipStream_t st, uint32_t* redo_list, uint32_t* redo_count) {
@@ -2083,48 +2179,48 @@ hipError_t wf_conn_ordered(const SceneDev& sc, const GpuCamera& cam, const WfBuf
 
 hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t count_imm, uint32_t* cursor,
                       const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    return launch_traverse<true>(sc, wb, nullptr, shadow_count, count_imm, cursor, cfg, stats, st);
+    return launch_traverse<true>(sc, wb, shadow_count, count_imm, cursor, cfg, stats, st);
 }
 
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
                     const uint32_t* queue_in, const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
-                    uint32_t* count_out, bool last_bounce, bool store_vertices, const WfLaunchCfg& cfg, unsigned long long* stats,
-                    hipStream_t st) {
+                    uint32_t* count_out, bool last_bounce, bool store_vertices, bool keep_draw_counts, const WfLaunchCfg& cfg,
+                    unsigned long long* stats, hipStream_t st) {
     dim3 grid(cfg.stream_blocks), block(kStageBlock);
-    const int last = last_bounce ? 1 : 0, keep = store_vertices ? 1 : 0;
+    const int last = last_bounce ? 1 : 0, keep = store_vertices ? 1 : 0, draws = keep_draw_counts ? 1 : 0;
     if (cfg.ordered) {
-        if (eye) hipLaunchKernelGGL((k_shade<true, false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
-        else hipLaunchKernelGGL((k_shade<false, false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        if (eye) hipLaunchKernelGGL((k_shade<true, false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+        else hipLaunchKernelGGL((k_shade<false, false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
         return hipGetLastError();
     }
     if (cfg.textured) {
         if (eye) {
-            if (stats) hipLaunchKernelGGL((k_shade<true, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
-            else hipLaunchKernelGGL((k_shade<true, false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+            if (stats) hipLaunchKernelGGL((k_shade<true, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+            else hipLaunchKernelGGL((k_shade<true, false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
         } else {
-            if (stats) hipLaunchKernelGGL((k_shade<false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
-            else hipLaunchKernelGGL((k_shade<false, false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+            if (stats) hipLaunchKernelGGL((k_shade<false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+            else hipLaunchKernelGGL((k_shade<false, false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
         }
         return hipGetLastError();
     }
     if (cfg.instanced) {
         if (eye) {
-            if (stats) hipLaunchKernelGGL((k_shade<true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
-            else hipLaunchKernelGGL((k_shade<true, false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+            if (stats) hipLaunchKernelGGL((k_shade<true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+            else hipLaunchKernelGGL((k_shade<true, false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
         } else {
-            if (stats) hipLaunchKernelGGL((k_shade<false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
-            else hipLaunchKernelGGL((k_shade<false, false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+            if (stats) hipLaunchKernelGGL((k_shade<false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+            else hipLaunchKernelGGL((k_shade<false, false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
         }
         return hipGetLastError();
     }
     if (eye) {
-        if (stats) hipLaunchKernelGGL((k_shade<true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
-        else if (store_vertices) hipLaunchKernelGGL((k_shade<true, false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        if (stats) hipLaunchKernelGGL((k_shade<true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+        else if (store_vertices) hipLaunchKernelGGL((k_shade<true, false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
         // no vertex is stored <=> the scene has no lambertian triangle: the variant without that material's code
-        else hipLaunchKernelGGL((k_shade<true, false, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        else hipLaunchKernelGGL((k_shade<true, false, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
     } else {
-        if (stats) hipLaunchKernelGGL((k_shade<false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
-        else hipLaunchKernelGGL((k_shade<false, false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, stats);
+        if (stats) hipLaunchKernelGGL((k_shade<false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+        else hipLaunchKernelGGL((k_shade<false, false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
     }
     return hipGetLastError();
 }
@@ -2165,7 +2261,7 @@ hipError_t wf_conn_count(const WfBuffers& wb, uint32_t n_slots, const WfLaunchCf
 }
 
 hipError_t wf_conn_plan(const WfBuffers& wb, uint32_t n_slots, const WfLaunchCfg& cfg, hipStream_t st) {
-    hipLaunchKernelGGL(k_conn_plan, dim3(1), dim3(kBlock), 0, st, wb, (n_slots + kConnTile - 1) / kConnTile, cfg.conn_pass_pairs, cfg.conn_passes);
+    hipLaunchKernelGGL(k_conn_plan, dim3(1), dim3(kPlanBlock), 0, st, wb, (n_slots + kConnTile - 1) / kConnTile, cfg.conn_pass_pairs, cfg.conn_passes);
     return hipGetLastError();
 }
 
