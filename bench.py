@@ -656,7 +656,7 @@ def main():
         ctx.set_workspace_limit(0)
         dflt_elapsed, _ = time_frames(scene, cam, fb, args.steps, 1, args.seed, stream)
         out["value_default_workspace"] = samples_per_step * args.steps / dflt_elapsed / 1e6
-        out["config"]["workspace"] = {"value": "bdpt_context_set_workspace_limit(176 GB): batches of up to 2^26 samples",
+        out["config"]["workspace"] = {"value": "bdpt_context_set_workspace_limit(176 GB): batches of up to 2^27 samples",
                                       "value_default_workspace": "library default (32 GiB, at most a quarter of the free memory)"}
         ctx.set_workspace_limit(int(os.environ.get("BDPT_BENCH_WORKSPACE_GB", "176")) << 30)
 

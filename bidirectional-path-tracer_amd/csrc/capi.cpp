@@ -76,7 +76,7 @@ Knobs read_knobs() {
     Knobs k;
     k.budget_gb = env_int("BDPT_WF_BUDGET_GB", 0, 0, 224);
     k.streams = env_int("BDPT_WF_STREAMS", 4, 1, kWfStreams);
-    k.batch_log2 = env_int("BDPT_WF_BATCH_LOG2", 26, 6, 30);
+    k.batch_log2 = env_int("BDPT_WF_BATCH_LOG2", 27, 6, 30);
     k.lds_kb = env_int("BDPT_WF_LDS_KB", 16, 1, 128);
     k.lds_stack = env_int("BDPT_WF_LDS_STACK", 8, 0, kQuadStackEntries);
     k.blocks_per_cu = env_int("BDPT_WF_BLOCKS_PER_CU", 0, 0, 16);
@@ -448,7 +448,10 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         return fail(BDPT_ERR_UNSUPPORTED, fixed_ws ? "the samples of one pixel exceed the static workspace (samples per pixel x depth too large for bdpt_render_device_static)"
                                                    : "samples per pixel exceed the wavefront batch capacity");
     int64_t ns_target = (int64_t)((budget / want_streams - per_stream_overhead) / per_slot);
-    const int64_t ns_cap = (int64_t)1 << kn.batch_log2;
+    int64_t ns_cap = (int64_t)1 << kn.batch_log2;
+    // (queue entries are numbered with 32 bits: 2^31 of them leave room for the pieces the waves take)
+    if (conn_queue && (double)ns_cap * cap_per_slot * (4.0 / 3.0 + 0.25) > 2147483648.0)
+        ns_cap = (int64_t)(2147483648.0 / (cap_per_slot * (4.0 / 3.0 + 0.25)));
     if (ns_target > ns_cap) ns_target = ns_cap;
     if (spp > ns_target) return fail(BDPT_ERR_UNSUPPORTED, "samples per pixel exceed the wavefront batch capacity");
     int64_t pixels_per_batch = ns_target / spp;

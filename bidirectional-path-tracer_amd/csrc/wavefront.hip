@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void k_gen_eye(GpuCamera cam, WfBuffers wb,
         camera_ray(cam, i, j, s_i, s_j, rng, o, d);
         wb.ray[slot] = o.x; wb.ray[wb.ns + slot] = o.y; wb.ray[2 * wb.ns + slot] = o.z;
         wb.ray[3 * wb.ns + slot] = d.x; wb.ray[4 * wb.ns + slot] = d.y; wb.ray[5 * wb.ns + slot] = d.z;
-        wb.thr[slot] = 1.0; wb.thr[wb.ns + slot] = 1.0; wb.thr[2 * wb.ns + slot] = 1.0;
+        // (the throughput of a camera ray is 1, camera.h:303: the first shading launch knows and does not read it)
         wb.ctrq[slot] = rng.counter;
         wb.ctr[slot] = rng.counter;       // (what stands when no bounce follows: max_depth 0)
     }
@@ -1126,7 +1126,8 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             const bool medium = MEDIA && pos <= kHitMedium0;
             double t_hit = 0.0;
             if (pos >= 0 || medium) t_hit = wb.hit[k];        // (k_redo has resolved the rays the traversal kernel left open)
-            V3 T = mk(wb.thr[k], wb.thr[ns + k], wb.thr[2 * ns + k]);
+            // (no queue: the camera rays themselves, throughput 1)
+            V3 T = (EYE && !queue_in) ? mk(1.0, 1.0, 1.0) : mk(wb.thr[k], wb.thr[ns + k], wb.thr[2 * ns + k]);
             const uint32_t ctr0 = wb.ctrq[k];
             if (pos < 0 && !medium) {
                 if (EYE) {   // camera.h:337-338: background_contrib (0) += throughput * background
