@@ -346,6 +346,38 @@ def test_large_scene_uses_global_memory_path(scenes, ctx, oracle):
     sc.close()
 
 
+@pytest.mark.parametrize("depth", [70, 300, 1200])
+def test_deep_paths(scenes, ctx, oracle, depth):
+    """max_depth far beyond the usual: a sample may have depth x depth pairs (rounds of their own in the connection kernel,
+    larger pieces of the shadow queue), the 2 x depth vertex records of one sample decide how many the kernel stages at a
+    time and with how many waves (depth 300: one wave per workgroup), and at depth 1200 they no longer fit a compute
+    unit's LDS: that render takes the single-kernel path.  A closed room, so that paths do get long."""
+    flat = scenes.FlatScene()
+    grey = flat.add_material(scenes.Material(scenes.LAMBERTIAN, (.7, .7, .7)))
+    red = flat.add_material(scenes.Material(scenes.LAMBERTIAN, (.7, .3, .3)))
+    light = flat.add_material(scenes.Material(scenes.DIFFUSE_LIGHT, (30.0, 30.0, 30.0)))
+    scenes.add_quad_triangles(flat, (0, 0, 0), (4, 0, 0), (0, 0, 4), grey)        # floor, ceiling, four walls: nothing escapes
+    scenes.add_quad_triangles(flat, (0, 3, 0), (0, 0, 4), (4, 0, 0), grey)
+    scenes.add_quad_triangles(flat, (0, 0, 0), (0, 3, 0), (4, 0, 0), red)
+    scenes.add_quad_triangles(flat, (0, 0, 4), (4, 0, 0), (0, 3, 0), grey)
+    scenes.add_quad_triangles(flat, (0, 0, 0), (0, 0, 4), (0, 3, 0), grey)
+    scenes.add_quad_triangles(flat, (4, 0, 0), (0, 3, 0), (0, 0, 4), red)
+    scenes.add_quad_triangles(flat, (1.9, 2.99, 1.9), (0.2, 0, 0), (0, 0, 0.2), light)
+    W, spp = {70: (6, 4), 300: (4, 4), 1200: (3, 1)}[depth]
+    flat.camera = scenes.Camera(aspect_ratio=1.0, image_width=W, samples_per_pixel=spp, max_depth=depth, background=(0, 0, 0), vfov=70,
+                                lookfrom=(2, 1.5, 0.2), lookat=(2, 1.2, 3), vup=(0, 1, 0))
+    sc = ctx.scene(flat)
+    cam = capi.camera_initialize(flat.camera)
+    fb, st = sc.render(cam, seed=29, want_stats="work") if depth <= 300 else (sc.render(cam, seed=29), None)
+    ofb, ostats, _ = oracle.scene(flat).render(cam.as_array(), W, cam.sqrt_spp, depth, 29, (0, 0, W, cam.image_height))
+    assert ofb.max() > 0
+    assert_bit_equal(fb, ofb, "depth %d" % depth)
+    assert_bit_equal(sc.render(cam, seed=29), ofb, "depth %d, without counters" % depth)
+    if st is not None:
+        assert st.connection_pairs > 64 * st.samples        # (samples with more pairs than a wave has lanes)
+    sc.close()
+
+
 def test_largest_scene_staged_in_lds(scenes, ctx, oracle):
     """484 triangles: hierarchy + triangles still fit the 64 KiB the traversal kernels stage completely, and the copy of
     the reference's tree beside them (967 nodes) takes the dynamic LDS of the visibility traversal to ~140 KiB and of
