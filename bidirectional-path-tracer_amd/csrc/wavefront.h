@@ -81,7 +81,8 @@ struct WfBatch {
     int32_t row_w, x0;        // owned column range
     int64_t first_pixel;      // ordinal (in owned-pixel order) of the batch's first pixel
     int32_t n_pixels;         // pixels in this batch
-    int32_t pixels_stride;    // slot = s * pixels_stride + p
+    int32_t pixels_stride;    // sample_stride 1: slot = s * pixels_stride + p (neighbouring slots: one stratum of neighbouring pixels)
+    int32_t sample_stride;    // otherwise = spp: slot = p * spp + s (neighbouring slots: the strata of one pixel)
     int64_t n_owned;
 };
 
@@ -105,6 +106,7 @@ struct WfLaunchCfg {
     uint32_t conn_chunk;      // queue entries a wave takes at a time (>= the pairs of one sample, depth x depth)
     uint32_t conn_passes;     // passes the host launches; pass p handles the tiles pass_bounds[p] .. pass_bounds[p + 1]
     unsigned long long conn_pass_pairs;   // most candidate pairs the planner gives one pass (what the queue holds for certain)
+    int sort_shift;           // k_shade orders the paths of a tile that go on by (leaf position >> sort_shift), at most 64 cells; -1: not at all
     bool own_test;        // k_connect tests the light vertex's own triangle (from tables in LDS) and keeps the pairs' contributions
     size_t lds_bytes;
     size_t ref_tree_bytes;    // LDS copy of the reference's tree (nodes + parents) for scenes staged in LDS

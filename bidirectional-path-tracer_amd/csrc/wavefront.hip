@@ -79,6 +79,36 @@ BDPT_DEV void tile_append_at(const bool (&flag)[kStagePerThread], const uint32_t
     __syncthreads();
 }
 
+// The same, with the flagged entries of the tile ordered by a small key (stable only between keys): entries with equal keys
+// end up next to one another in the queue.  The order of a queue does not touch any result - samples do not interact -
+// only which rays share a wave of the traversal kernel.
+constexpr uint32_t kSortBins = 64;
+BDPT_DEV void tile_append_sorted(const bool (&flag)[kStagePerThread], const uint32_t (&value)[kStagePerThread], const uint32_t (&key)[kStagePerThread],
+                                 uint32_t* queue, uint32_t* count, uint32_t* s_hist, uint32_t* s_base, uint32_t (&at)[kStagePerThread]) {
+    for (uint32_t i = threadIdx.x; i < kSortBins; i += kStageBlock) s_hist[i] = 0u;
+    __syncthreads();
+    uint32_t rank[kStagePerThread];
+#pragma unroll
+    for (int j = 0; j < kStagePerThread; j++) rank[j] = flag[j] ? atomicAdd(&s_hist[key[j]], 1u) : 0u;
+    __syncthreads();
+    if (threadIdx.x < 64u) {              // first wave: exclusive running sums of the bins (kSortBins == 64: one bin per lane)
+        const uint32_t mine = s_hist[threadIdx.x];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if ((int)threadIdx.x >= off) incl += v;
+        }
+        s_hist[threadIdx.x] = incl - mine;
+        if (threadIdx.x == 63u) *s_base = incl ? atomicAdd(count, incl) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kStagePerThread; j++)
+        if (flag[j]) { at[j] = *s_base + s_hist[key[j]] + rank[j]; queue[at[j]] = value[j]; }
+    __syncthreads();
+}
+
 BDPT_DEV void flush_wave_counter(unsigned long long* dst, unsigned long long x) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
@@ -89,8 +119,9 @@ BDPT_DEV void flush_wave_counter(unsigned long long* dst, unsigned long long x) 
 BDPT_DEV bool slot_to_sample(const GpuCamera& cam, const WfBatch& b, uint32_t slot, int& i, int& j, int& s) {
     // 32-bit arithmetic throughout (the host guarantees fewer than 2^31 owned pixels): 64-bit integer
     // division is a long software sequence on the GPU
-    const uint32_t sv = slot / (uint32_t)b.pixels_stride;
-    const uint32_t p = slot - sv * (uint32_t)b.pixels_stride;
+    uint32_t sv, p;
+    if (b.sample_stride > 1) { p = slot / (uint32_t)b.sample_stride; sv = slot - p * (uint32_t)b.sample_stride; }
+    else { sv = slot / (uint32_t)b.pixels_stride; p = slot - sv * (uint32_t)b.pixels_stride; }
     s = (int)sv;
     const uint32_t q = (uint32_t)b.first_pixel + p;
     if (p >= (uint32_t)b.n_pixels || q >= (uint32_t)b.n_owned) return false;
@@ -1089,8 +1120,9 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_ordered(SceneDev sc, GpuCa
 template <bool EYE, bool STATS, bool LAMBERT, bool INSTANCED = false, bool TEX = false, bool MEDIA = false>
 __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
                                                   const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
-                                                  uint32_t* count_out, int last_bounce, int store_vertices, int keep_draws, unsigned long long* stats) {
-    __shared__ uint32_t s_wave[kStageWaves];
+                                                  uint32_t* count_out, int last_bounce, int store_vertices, int keep_draws, int sort_shift,
+                                                  unsigned long long* stats) {
+    __shared__ uint32_t s_wave[kSortBins > kStageWaves ? kSortBins : kStageWaves];
     __shared__ uint32_t s_base;
     const uint32_t count = count_in_ptr ? *count_in_ptr : count_in_imm;
     const uint64_t ns = wb.ns;
@@ -1098,13 +1130,14 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
     uint32_t n_stored = 0;
     // whole workgroups iterate together so that the append sees every thread
     for (uint32_t tile = blockIdx.x * kStageTile; tile < count; tile += gridDim.x * kStageTile) {
-        uint32_t slots[kStagePerThread], at[kStagePerThread];
+        uint32_t slots[kStagePerThread], at[kStagePerThread], key[kStagePerThread];
         bool may_go_on[kStagePerThread];
 #pragma unroll
         for (int j = 0; j < kStagePerThread; j++) {
             const uint32_t k = tile + (uint32_t)j * kStageBlock + threadIdx.x;
             slots[j] = kDeadSlot;
             at[j] = 0;
+            key[j] = 0;
             may_go_on[j] = false;
             if (k >= count) continue;
             const uint32_t slot = queue_in ? queue_in[k] : k;
@@ -1114,9 +1147,16 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
             if (last_bounce) continue;
             const int32_t pos = wb.hit_tri[k];
             if (MEDIA && pos <= kHitMedium0) may_go_on[j] = true;                   // the phase function of a medium always scatters
-            else if (pos >= 0) may_go_on[j] = (sc.shade[pos].mat >> 30) != 3u;      // every material but an emitter may
+            else if (pos >= 0) {
+                may_go_on[j] = (sc.shade[pos].mat >> 30) != 3u;                     // every material but an emitter may
+                // paths that leave from the same part of the scene become neighbours in the next queue (the positions of
+                // the reference's leaf order follow its spatial median splits)
+                const uint32_t cell = (uint32_t)pos >> (sort_shift < 0 ? 0 : sort_shift);
+                key[j] = cell < kSortBins ? cell : kSortBins - 1u;
+            }
         }
-        tile_append_at(may_go_on, slots, queue_out, count_out, s_wave, &s_base, at);
+        if (sort_shift >= 0) tile_append_sorted(may_go_on, slots, key, queue_out, count_out, s_wave, &s_base, at);
+        else tile_append_at(may_go_on, slots, queue_out, count_out, s_wave, &s_base, at);
 #pragma unroll 1
         for (int j = 0; j < kStagePerThread; j++) {
             const uint32_t k = tile + (uint32_t)j * kStageBlock + threadIdx.x;
@@ -1874,18 +1914,20 @@ __global__ __launch_bounds__(kBlock) void k_resolve(GpuCamera cam, WfBuffers wb,
         const int p = (int)(t - (uint32_t)ch * (uint32_t)b.n_pixels);
         const uint32_t q = (uint32_t)b.first_pixel + (uint32_t)p;
         if (q >= (uint32_t)b.n_owned) continue;
-        const double* src = wb.result + (uint64_t)ch * wb.ns + p;
+        const bool by_pixel = b.sample_stride > 1;
+        const double* src = wb.result + (uint64_t)ch * wb.ns + (by_pixel ? (uint64_t)p * (uint64_t)spp : (uint64_t)p);
+        const uint64_t step = by_pixel ? 1u : (uint64_t)b.pixels_stride;
         // the additions are sequential (the reference's order); the loads are not: sixteen in flight at a time
         double acc = 0.0;
         int s = 0;
         for (; s + 16 <= spp; s += 16) {
             double v[16];
 #pragma unroll
-            for (int q = 0; q < 16; q++) v[q] = src[(uint64_t)(s + q) * b.pixels_stride];
+            for (int q = 0; q < 16; q++) v[q] = src[(uint64_t)(s + q) * step];
 #pragma unroll
             for (int q = 0; q < 16; q++) acc = acc + v[q];
         }
-        for (; s < spp; s++) acc = acc + src[(uint64_t)s * b.pixels_stride];
+        for (; s < spp; s++) acc = acc + src[(uint64_t)s * step];
         const uint32_t row = q / (uint32_t)b.row_w;
         const int j = b.rows[row];
         const int i = b.x0 + (int)(q - row * (uint32_t)b.row_w);
@@ -2190,38 +2232,38 @@ hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& w
     dim3 grid(cfg.stream_blocks), block(kStageBlock);
     const int last = last_bounce ? 1 : 0, keep = store_vertices ? 1 : 0, draws = keep_draw_counts ? 1 : 0;
     if (cfg.ordered) {
-        if (eye) hipLaunchKernelGGL((k_shade<true, false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
-        else hipLaunchKernelGGL((k_shade<false, false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+        if (eye) hipLaunchKernelGGL((k_shade<true, false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
+        else hipLaunchKernelGGL((k_shade<false, false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
         return hipGetLastError();
     }
     if (cfg.textured) {
         if (eye) {
-            if (stats) hipLaunchKernelGGL((k_shade<true, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
-            else hipLaunchKernelGGL((k_shade<true, false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+            if (stats) hipLaunchKernelGGL((k_shade<true, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
+            else hipLaunchKernelGGL((k_shade<true, false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
         } else {
-            if (stats) hipLaunchKernelGGL((k_shade<false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
-            else hipLaunchKernelGGL((k_shade<false, false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+            if (stats) hipLaunchKernelGGL((k_shade<false, true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
+            else hipLaunchKernelGGL((k_shade<false, false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
         }
         return hipGetLastError();
     }
     if (cfg.instanced) {
         if (eye) {
-            if (stats) hipLaunchKernelGGL((k_shade<true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
-            else hipLaunchKernelGGL((k_shade<true, false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+            if (stats) hipLaunchKernelGGL((k_shade<true, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
+            else hipLaunchKernelGGL((k_shade<true, false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
         } else {
-            if (stats) hipLaunchKernelGGL((k_shade<false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
-            else hipLaunchKernelGGL((k_shade<false, false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+            if (stats) hipLaunchKernelGGL((k_shade<false, true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
+            else hipLaunchKernelGGL((k_shade<false, false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
         }
         return hipGetLastError();
     }
     if (eye) {
-        if (stats) hipLaunchKernelGGL((k_shade<true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
-        else if (store_vertices) hipLaunchKernelGGL((k_shade<true, false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+        if (stats) hipLaunchKernelGGL((k_shade<true, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
+        else if (store_vertices) hipLaunchKernelGGL((k_shade<true, false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
         // no vertex is stored <=> the scene has no lambertian triangle: the variant without that material's code
-        else hipLaunchKernelGGL((k_shade<true, false, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+        else hipLaunchKernelGGL((k_shade<true, false, false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
     } else {
-        if (stats) hipLaunchKernelGGL((k_shade<false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
-        else hipLaunchKernelGGL((k_shade<false, false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, stats);
+        if (stats) hipLaunchKernelGGL((k_shade<false, true, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
+        else hipLaunchKernelGGL((k_shade<false, false, true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm, queue_out, count_out, last, keep, draws, cfg.sort_shift, stats);
     }
     return hipGetLastError();
 }

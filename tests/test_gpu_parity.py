@@ -500,6 +500,12 @@ WF_SETTINGS = [
     {"BDPT_WF_BUDGET_GB": "1"},
     {"BDPT_WF_NO_FIRST_LEAF": "1"},                               # shadow rays start at the root (large scenes: the default tests the far end's triangle first)
     {"BDPT_WF_NO_FIRST_LEAF": "1", "BDPT_WF_LDS_STACK": "0"},
+    {"BDPT_WF_PIXEL_MAJOR": "1"}, {"BDPT_WF_PIXEL_MAJOR": "0"},   # which samples are neighbours in the queues
+    {"BDPT_WF_PIXEL_MAJOR": "1", "BDPT_WF_BATCH_LOG2": "12", "BDPT_WF_STREAMS": "2"},
+    {"BDPT_WF_CONN_BUDGET": "16", "BDPT_WF_CONN_CAP": "5"},      # connection kernel: few records staged at a time, many passes
+    {"BDPT_WF_CONN_BUDGET": "512", "BDPT_WF_CONN_CAP": "40"},
+    {"BDPT_WF_REDO_BLOCKS": "7"},
+    {"BDPT_WF_SORT_CELLS": "64"}, {"BDPT_WF_SORT_CELLS": "5", "BDPT_WF_PIXEL_MAJOR": "0"}, {"BDPT_WF_SORT_CELLS": "0"},
 ]
 
 
