@@ -358,7 +358,8 @@ def spawn_ranks(args):
 
 
 # ------------------------------------------------------------------------------------------ timing
-def time_frames(scene, cam, fb, steps, warmup, seed, stream, rank=0, world=1, shard_rows=4, dist=None, megakernel=False, reduce_ms=None):
+def time_frames(scene, cam, fb, steps, warmup, seed, stream, rank=0, world=1, shard_rows=4, dist=None, megakernel=False, reduce_ms=None,
+                unidirectional=False):
     """(elapsed seconds of `steps` frames, device ms of each timed frame).  Barrier + synchronize on both sides.
     reduce_ms: a list that receives the duration of every timed frame's all-reduce on this rank (world > 1)."""
     import torch
@@ -368,7 +369,8 @@ def time_frames(scene, cam, fb, steps, warmup, seed, stream, rank=0, world=1, sh
 
     def step(timed):
         def render_shard(buf, shard):
-            scene.render_device(cam, buf.data_ptr(), seed=seed, shard=shard, stream=stream, time_kernel=timed, megakernel=megakernel)
+            scene.render_device(cam, buf.data_ptr(), seed=seed, shard=shard, stream=stream, time_kernel=timed, megakernel=megakernel,
+                                unidirectional=unidirectional)
             if timed:
                 kernel_ms.append(scene.last_kernel_ms())   # waits for the kernel's stop event
         distributed.render_frame(render_shard, fb, rank, world, shard_rows, dist, reduce_events if timed else None)
@@ -411,7 +413,7 @@ def oracle_parity(flat, cam, fb, seed, pixels):
             "pixels_bit_identical": same, "max_per_pixel_l2_of_mean_radiance": worst}
 
 
-def extra_leg(ctx, name, seed, steps, stream, parity_pixels):
+def extra_leg(ctx, name, seed, steps, stream, parity_pixels, unidirectional_too=False):
     import torch
     capi = importlib.import_module(PKG + ".capi")
     t0 = time.perf_counter()
@@ -428,6 +430,11 @@ def extra_leg(ctx, name, seed, steps, stream, parity_pixels):
     if parity_pixels:
         out["parity"] = oracle_parity(flat, cam, fb, seed, [(int((a + 0.5) * W / parity_pixels), int((a * 7 % parity_pixels + 0.5) * H / parity_pixels))
                                                             for a in range(parity_pixels)])
+    if unidirectional_too:
+        # the reference's other estimator (camera::path_trace_color, src/camera.h:255-292) on the same pipeline
+        elapsed, _ = time_frames(scene, cam, fb, steps, 1, seed, stream, unidirectional=True)
+        out["unidirectional"] = {"value": W * H * spp_used * depth * steps / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": elapsed / steps * 1e3,
+                                 "estimator": "camera::path_trace_color (BDPT_RENDER_UNIDIRECTIONAL)"}
     scene.close()
     return out
 
@@ -666,7 +673,7 @@ def main():
         extras = {}
         for name, pixels in (("cornell-512", 16), ("coffee-machine-1080p", 16), ("sphere-lattice-10m-4096", 16), ("sphere-lattice-instanced-10m-4096", 16)):
             try:
-                extras[name] = extra_leg(ctx, name, args.seed, 3 if name == "cornell-512" else 2, stream, pixels)
+                extras[name] = extra_leg(ctx, name, args.seed, 3 if name == "cornell-512" else 2, stream, pixels, unidirectional_too=(name == "cornell-512"))
             except Exception as e:      # the headline line must not depend on an extra
                 extras[name] = {"error": repr(e)}
         out["extra"] = extras

@@ -444,14 +444,14 @@ class Scene:
         return (fb, st) if want_stats else fb
 
     def render_device(self, cam_state: CameraState, d_framebuffer: int, seed=0, rect=None, shard=(0, 1, 1),
-                      want_stats=False, stream: int = 0, time_kernel=False, megakernel=False, time_stages=False):
+                      want_stats=False, stream: int = 0, time_kernel=False, megakernel=False, time_stages=False, unidirectional=False):
         """Framebuffer already in device memory (`d_framebuffer` = device pointer, e.g. tensor.data_ptr())."""
         p = RenderParams()
         p.seed = seed
         if rect is not None:
             p.x0, p.y0, p.x1, p.y1 = [int(v) for v in rect]
         p.shard_index, p.shard_count, p.shard_rows = shard
-        p.flags = self._flags(want_stats, time_kernel, megakernel, time_stages)
+        p.flags = self._flags(want_stats, time_kernel, megakernel, time_stages, unidirectional)
         _check(self.lib.bdpt_render_device(self.ctx.h, self.h, C.byref(cam_state), C.byref(p), C.c_void_p(d_framebuffer),
                                            C.c_void_p(stream)))
 

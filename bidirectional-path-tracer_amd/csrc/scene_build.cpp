@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
+#include <unordered_map>
 
 namespace bdpt {
 namespace {
@@ -50,6 +52,21 @@ inline int longest_axis(const Box3& b) {   // aabb.h:68-75
     return sy > sz ? 1 : 2;
 }
 
+// Host threads a scene build may use (BDPT_BUILD_THREADS; by default what the machine reports, at most 16).  The two
+// builders below split into independent subtrees; which thread builds which subtree changes nothing of the result.
+inline unsigned build_threads() {
+    if (const char* v = std::getenv("BDPT_BUILD_THREADS")) { const int n = std::atoi(v); return n < 1 ? 1u : (n > 64 ? 64u : (unsigned)n); }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw < 1 ? 1u : (hw > 16 ? 16u : hw);
+}
+// levels of the recursion at which both halves of a range of at least kParallelSpan are built by two threads
+inline int parallel_levels() {
+    int levels = 0;
+    for (unsigned t = build_threads(); t > 1; t >>= 1) levels++;
+    return levels;
+}
+constexpr size_t kParallelSpan = 1u << 15;
+
 struct Builder {
     const std::vector<BuildTri>& tris;
     std::vector<BuildNode> nodes;
@@ -57,7 +74,63 @@ struct Builder {
 
     explicit Builder(const std::vector<BuildTri>& t) : tris(t) {}
 
-    // bvh_node(objects, start, end), src/acceleration/bvh.h:20-48.  Nodes are emitted in pre-order.
+    // number of bvh_node objects over a span (bvh.h:29-46: one for a span of one or two, otherwise one plus the halves')
+    // (the halves of a span differ by at most one, so a tree has two distinct spans per level: the table is filled once,
+    // before any thread starts, and only read afterwards)
+    std::unordered_map<size_t, size_t> span_nodes;
+    size_t fill_span_nodes(size_t span) {
+        if (span <= 2) return 1;
+        auto it = span_nodes.find(span);
+        if (it != span_nodes.end()) return it->second;
+        const size_t n = 1 + fill_span_nodes(span / 2) + fill_span_nodes(span - span / 2);
+        span_nodes.emplace(span, n);
+        return n;
+    }
+    size_t nodes_of_span(size_t span) const { return span <= 2 ? 1 : span_nodes.at(span); }
+
+    // bvh_node(objects, start, end), src/acceleration/bvh.h:20-48, into the pre-order array: the node of a range is
+    // `idx`, its left subtree follows at idx + 1, its right one behind that (sizes known from the spans alone), so
+    // the two halves - each sorts its own part of `order` with the reference's own call - can be built side by side.
+    void build_at(size_t start, size_t end, size_t idx, int levels) {
+        const double inf = std::numeric_limits<double>::infinity();
+        Box3 box;                          // aabb::empty (aabb.h:92): padding leaves the infinities as they are
+        for (int k = 0; k < 3; k++) { box.lo[k] = inf; box.hi[k] = -inf; }
+        for (size_t i = start; i < end; i++) box = unite(box, tris[order[i]].box);
+        const int axis = longest_axis(box);
+        const size_t span = end - start;
+        int32_t left, right;
+        if (span == 1) {
+            left = right = ~(int32_t)order[start];
+        } else if (span == 2) {
+            left = ~(int32_t)order[start];
+            right = ~(int32_t)order[start + 1];
+        } else {
+            const std::vector<BuildTri>& t = tris;
+            std::sort(order.begin() + start, order.begin() + end,
+                      [&t, axis](uint32_t a, uint32_t b) { return t[a].box.lo[axis] < t[b].box.lo[axis]; });
+            const size_t mid = start + span / 2;
+            const size_t li = idx + 1, ri = li + nodes_of_span(mid - start);
+            if (levels > 0 && span >= kParallelSpan) {
+                std::thread other([this, start, mid, li, levels] { build_at(start, mid, li, levels - 1); });
+                build_at(mid, end, ri, levels - 1);
+                other.join();
+            } else {
+                build_at(start, mid, li, 0);
+                build_at(mid, end, ri, 0);
+            }
+            left = (int32_t)li;
+            right = (int32_t)ri;
+        }
+        nodes[idx].box = box;
+        nodes[idx].left = left;
+        nodes[idx].right = right;
+    }
+    void build_all(size_t n) {
+        nodes.assign(fill_span_nodes(n), BuildNode());
+        build_at(0, n, 0, parallel_levels());
+    }
+
+    // the same, nodes appended one by one (small trees: the objects of a composite scene)
     int32_t build(size_t start, size_t end) {
         const int32_t idx = (int32_t)nodes.size();
         nodes.push_back(BuildNode());
@@ -118,12 +191,37 @@ inline float round_up(double x) {
 }
 
 struct SahBuilder {
-    std::vector<SahRef> refs;
+    std::vector<SahRef> own_refs;
+    std::vector<SahRef>& refs;             // own_refs, or those of the builder this one works for
     std::vector<SahBinNode> nodes;
     std::vector<uint32_t> leaf_order;      // positions (in stris) in this hierarchy's leaf order
     uint32_t max_depth = 0;
     size_t min_leaf = 2;       // ranges of at most this many triangles always become a leaf
     double box_cost = 1.0;     // cost of one record visit in units of one triangle test
+    int parallel_levels_left = 0;
+
+    SahBuilder() : refs(own_refs), parallel_levels_left(parallel_levels()) {}
+    // a helper over part of `parent`'s references
+    SahBuilder(SahBuilder& parent, int levels) : refs(parent.refs), min_leaf(parent.min_leaf), box_cost(parent.box_cost), parallel_levels_left(levels) {}
+    SahBuilder(const SahBuilder&) = delete;
+
+    // Appends what `part` built: its records (interior child references and leaf references moved behind this builder's
+    // own) and its leaf order.  `ref`: the child reference `part` returned for its range; returns it as this builder's.
+    int32_t adopt(const SahBuilder& part, int32_t ref) {
+        const int32_t node_off = (int32_t)nodes.size();
+        const uint32_t leaf_off = (uint32_t)leaf_order.size();
+        auto moved = [node_off, leaf_off](int32_t r) -> int32_t {
+            if (r >= 0) return r + node_off;
+            if (r == kQuadEmpty) return r;
+            const uint32_t code = (uint32_t)~r;
+            return ~(int32_t)((((code >> 2) + leaf_off) << 2) | (code & 3u));
+        };
+        nodes.reserve(nodes.size() + part.nodes.size());
+        for (SahBinNode nd : part.nodes) { nd.child0 = moved(nd.child0); nd.child1 = moved(nd.child1); nodes.push_back(nd); }
+        leaf_order.insert(leaf_order.end(), part.leaf_order.begin(), part.leaf_order.end());
+        if (part.max_depth > max_depth) max_depth = part.max_depth;
+        return moved(ref);
+    }
 
     static double area(const double* lo, const double* hi) {
         const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -214,8 +312,23 @@ struct SahBuilder {
         double lo0[3], hi0[3], lo1[3], hi1[3];
         bounds(a, mid, lo0, hi0);
         bounds(mid, b, lo1, hi1);
-        const int32_t c0r = build(a, mid, depth + 1);
-        const int32_t c1r = build(mid, b, depth + 1);
+        int32_t c0r, c1r;
+        if (parallel_levels_left > 0 && n >= kParallelSpan) {
+            // Both halves at once: the right one by a builder of its own over the same `refs` (the ranges are disjoint),
+            // whose records and leaf order are appended behind the left half's afterwards - the order in which one thread
+            // alone would have produced them.
+            SahBuilder right(*this, parallel_levels_left - 1);
+            int32_t right_ref = 0;
+            std::thread other([&right, &right_ref, mid, b, depth] { right_ref = right.build(mid, b, depth + 1); });
+            parallel_levels_left--;
+            c0r = build(a, mid, depth + 1);
+            parallel_levels_left++;
+            other.join();
+            c1r = adopt(right, right_ref);
+        } else {
+            c0r = build(a, mid, depth + 1);
+            c1r = build(mid, b, depth + 1);
+        }
         SahBinNode& nd = nodes[idx];
         for (int k = 0; k < 3; k++) {
             nd.lo0[k] = round_down(lo0[k]); nd.hi0[k] = round_up(hi0[k]);
@@ -490,8 +603,7 @@ std::string build_host_scene(const double* tv, const int32_t* tri_material, uint
     Builder b(btris);
     b.order.resize(n_tri);
     for (uint32_t i = 0; i < n_tri; i++) b.order[i] = i;
-    b.nodes.reserve(n_tri);
-    b.build(0, n_tri);
+    b.build_all(n_tri);
 
     // thread the pre-order array: skip = first node after the subtree
     const uint32_t n_nodes = (uint32_t)b.nodes.size();
