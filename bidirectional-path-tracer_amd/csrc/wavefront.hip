@@ -2202,6 +2202,9 @@ hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* co
 }
 
 hipError_t wf_redo(const SceneDev& sc, const WfBuffers& wb, const WfLaunchCfg& cfg, hipStream_t st, uint32_t* redo_list, uint32_t* redo_count) {
+#ifdef BDPT_AB_SKIP_REDO
+    return hipSuccess;      // timing experiment only (wrong pixels): what the frame would gain if k_redo cost nothing
+#endif
     // few rays, if any: a small grid that returns at once when the list is empty
     if (cfg.instanced) hipLaunchKernelGGL(k_redo<true>, dim3(cfg.redo_blocks), dim3(kBlock), 0, st, sc, wb, redo_list, redo_count);
     else hipLaunchKernelGGL(k_redo<false>, dim3(cfg.redo_blocks), dim3(kBlock), 0, st, sc, wb, redo_list, redo_count);
