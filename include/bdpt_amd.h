@@ -291,8 +291,8 @@ int bdpt_render_device(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_ca
  * nothing - the table of owned rows and the per-sample path state live in a workspace of 256 MiB that is part of the
  * library's code object (every GPU the library runs on holds its copy until the process ends), and the pipeline cuts
  * the frame into batches that fit it.  No counterpart in the reference.  Limits: the samples of ONE pixel must fit the
- * workspace - about samples x (152 + 240 x max_depth) bytes, e.g. 1024 samples at depth 12 need 3 MB, fine; 65536
- * samples at depth 40 do not - otherwise BDPT_ERR_UNSUPPORTED; flags other than BDPT_RENDER_COUNT_WORK,
+ * workspace - about samples x (220 + 290 x max_depth) + 21000 x max_depth x max_depth bytes, e.g. 1024 samples at depth
+ * 12 need 7 MB, fine; 65536 samples at depth 40 do not - otherwise BDPT_ERR_UNSUPPORTED; flags other than BDPT_RENDER_COUNT_WORK,
  * BDPT_RENDER_TIME_KERNEL and BDPT_RENDER_UNIDIRECTIONAL are refused (they need buffers of their own).  All calls on one
  * GPU share that GPU's workspace, whatever the context or stream: the library orders them itself - a call's work starts
  * after the previous call's has ended (one event per GPU, made when the first context is) - so they never overlap, and
