@@ -145,6 +145,7 @@ struct SceneDev {
     double bary_margin;             // a hit closer than this (in barycentric units) to its triangle's outline is re-checked
     uint32_t n_nodes, n_tris, n_mats, n_lights;
     uint32_t ref_nested;            // 1: every box of `nodes` contains the boxes of the nodes below it
+    uint32_t n_objs;                // entries of `objs`
     // Scenes with instances (translate / rotate_y objects over meshes of their own) on the pipeline.  `nodes` and
     // `node_parent` then hold the two-level table of such a scene (the world's tree, whose leaves are triangles or
     // objects, followed by one tree per mesh; every tree threaded by itself), `tris` of a mesh are in the mesh's own

@@ -66,6 +66,8 @@ struct Knobs {
     int leaf_inner;       // 0: half the leaf threshold
     int chunk;
     int no_first_leaf;    // 1: shadow rays start at the root like all others
+    int no_lds_scene;     // 1: small scenes are not staged in LDS (measuring)
+    int no_own_test;      // 1: the connection kernel leaves the far end's own triangle to the traversal (measuring)
     int first_leaf_mb;    // largest triangle table (MB) whose shadow rays test their far end's triangle first
     int redo_blocks;      // workgroups of k_redo; 0: one per compute unit
     int conn_cap_tenths;  // shadow-queue entries per sample slot, in tenths of max_depth (10: depth entries per slot)
@@ -87,6 +89,8 @@ Knobs read_knobs() {
     k.leaf_inner = env_int("BDPT_WF_LEAF_INNER", 0, 0, 64);
     k.chunk = env_int("BDPT_WF_CHUNK", 512, 1, 1 << 20);
     k.no_first_leaf = env_int("BDPT_WF_NO_FIRST_LEAF", 0, 0, 1);
+    k.no_lds_scene = env_int("BDPT_WF_NO_LDS_SCENE", 0, 0, 1);
+    k.no_own_test = env_int("BDPT_WF_NO_OWN_TEST", 0, 0, 1);
     k.first_leaf_mb = env_int("BDPT_WF_FIRST_LEAF_MB", 1 << 20, 0, 1 << 20);
     k.redo_blocks = env_int("BDPT_WF_REDO_BLOCKS", 0, 0, 1 << 16);
     k.conn_cap_tenths = env_int("BDPT_WF_CONN_CAP", 10, 5, 80);
@@ -297,14 +301,18 @@ bool pipeline_can_connect(const bdpt_scene* scene, int depth) {
 
 int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCfg& cfg, int depth = 1) {
     const Knobs& kn = ctx->knobs;
-    cfg.lds_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuQuadNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri);
-    cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit;
+    // (the hierarchy's triangle table: one entry per triangle, or per (object, triangle) pair of a scene with instances)
+    // (... and behind it, for such a scene, the objects and the object of every entry)
+    cfg.lds_bytes = (size_t)scene->dev.n_xnodes * sizeof(GpuQuadNode) + scene->host.xtris.size() * sizeof(GpuTri);
+    if (scene->dev.objs) cfg.lds_bytes = (cfg.lds_bytes + scene->dev.n_objs * sizeof(CxObject) + scene->host.xtris.size() * sizeof(int32_t) + 15) & ~(size_t)15;
+    cfg.lds_scene = cfg.lds_bytes <= kSceneLdsLimit && !kn.no_lds_scene;
     if (!cfg.lds_scene) cfg.lds_bytes = 0;
     cfg.instanced = scene->dev.objs != nullptr;
     cfg.textured = scene->dev.tex != nullptr;
     cfg.ordered = scene->ordered;
-    if (cfg.instanced) { cfg.lds_scene = false; cfg.lds_bytes = 0; }      // (the staged variants carry no instance code)
-    cfg.ref_tree_bytes = cfg.lds_scene ? (((size_t)scene->dev.n_nodes * (sizeof(GpuNode) + sizeof(uint32_t)) + 15) & ~(size_t)15) : 0;
+    if (cfg.ordered) { cfg.lds_scene = false; cfg.lds_bytes = 0; }        // (a scene with media has no such hierarchy)
+    // (a scene with instances keeps the reference's two-level tree in global memory)
+    cfg.ref_tree_bytes = cfg.lds_scene && !cfg.instanced ? (((size_t)scene->dev.n_nodes * (sizeof(GpuNode) + sizeof(uint32_t)) + 15) & ~(size_t)15) : 0;
     // the visibility instantiation of a staged scene holds scene, stack and the reference's tree at once: all of it has to
     // fit a compute unit's 160 KiB (it does up to ~520 triangles, which is where kSceneLdsLimit ends too)
     if (cfg.lds_scene && cfg.lds_bytes + (size_t)(kn.lds_stack + 1) * kBlock * sizeof(double) + cfg.ref_tree_bytes + 1024 > ((size_t)160 << 10)) {
@@ -312,8 +320,11 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     }
     // k_connect tests the far end's own triangle from tables in LDS (the reference's tree, triangles, grazing thresholds,
     // leaf nodes): for scenes where those are small beside the vertex records the kernel stages (up to ~70 triangles)
-    const size_t own_bytes = cfg.ref_tree_bytes + (size_t)scene->dev.n_tris * (sizeof(GpuTri) + 8);
-    cfg.own_test = cfg.lds_scene && own_bytes <= ((size_t)16 << 10);
+    // (a scene with instances: the hierarchy's own triangle table, the objects, and two words per entry)
+    cfg.n_entries = (uint32_t)scene->host.xtris.size();
+    const size_t own_bytes = cfg.instanced ? ((scene->host.xtris.size() * (sizeof(GpuTri) + 8) + scene->dev.n_objs * sizeof(CxObject) + 15) & ~(size_t)15)
+                                           : cfg.ref_tree_bytes + (size_t)scene->dev.n_tris * (sizeof(GpuTri) + 8);
+    cfg.own_test = cfg.lds_scene && own_bytes <= ((size_t)16 << 10) && !kn.no_own_test;
     {
         const uint32_t d = (uint32_t)(depth > 0 ? depth : 1);
         uint32_t budget = kn.conn_budget > 0 ? (uint32_t)kn.conn_budget : 128u;      // (measured: 96 and 160 are 2 % slower, 240 is 6 %)
@@ -926,6 +937,7 @@ int upload_pipeline_tables(bdpt_context* ctx, bdpt_scene* s) {
     d.n_mats = (uint32_t)h.mats.size();
     d.n_lights = s->composite ? h.n_lights : (uint32_t)h.light_tris.size();
     d.ref_nested = h.ref_nested ? 1u : 0u;
+    d.n_objs = (uint32_t)h.objs.size();
     const bool inst = h.vertex_names_entry;      // (instances, textures, media: the kernels of scenes with instances)
     d.objs = inst ? reinterpret_cast<const CxObject*>(base + off_objs) : nullptr;
     d.xobj = inst ? reinterpret_cast<const int32_t*>(base + off_xobj) : nullptr;

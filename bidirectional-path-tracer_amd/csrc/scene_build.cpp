@@ -502,33 +502,56 @@ static void build_traversal_hierarchy(HostScene& out, const std::vector<Box3>& w
             // box is not padded (triangle.h:38 builds it from two points); a bvh_node's is when it is thin
             // (aabb.h:26-32,81-88), so the boxes above a flat triangle come within 5e-5 of its plane or coincide with
             // it.  On an axis where the triangle is not thin, a hit away from its outline lies inside every box above it
-            // by the margin of wavefront.hip's exact rule: no bit.  An entry of a scene with instances: all bits.
-            // (an entry that belongs to an object: the chain runs through the mesh's boxes in the mesh's coordinates and
-            // through the world's in the world's; thin in neither, it has no such face, otherwise it keeps all bits)
-            const bool in_object = out.vertex_names_entry && out.pos_obj[sb.leaf_order[k]] >= 0;
-            int thin_world = 0;
-            for (int a = 0; a < 3; a++) thin_world += (world_box[sb.leaf_order[k]].hi[a] - world_box[sb.leaf_order[k]].lo[a] < 1e-4) ? 1 : 0;
-            uint32_t faces = (in_object && (thin_axes > 0 || thin_world > 0)) ? 63u : 0u;
+            // by the margin of wavefront.hip's exact rule: no bit.
             // ... and on which sides every such face lies EXACTLY in the plane of an exactly flat triangle: the plane's
             // coordinate is then the triangle's own, all those boxes give the same distance to it, and the kernels
             // settle the tie with the one product of aabb.h:49-50 that decides it
-            uint32_t inexact = 0u;
-            if (!in_object && thin_axes > 0) {
-                const Box3& tb = own_box[sb.leaf_order[k]];
+            const uint32_t pos = sb.leaf_order[k];
+            const int32_t ob = out.vertex_names_entry ? out.pos_obj[pos] : -1;
+            int thin_world = 0;
+            for (int a = 0; a < 3; a++) thin_world += (world_box[pos].hi[a] - world_box[pos].lo[a] < 1e-4) ? 1 : 0;
+            uint32_t faces = 0u, inexact = 0u;
+            // the boxes of one tree above `first` against the triangle's box `tb` in that tree's coordinates; `same`: the
+            // numbers of that tree's slab test on axis a are the very ones the kernels form (see below)
+            auto chain = [&](uint32_t first, const Box3& tb, const bool same[3]) {
                 // (boxes that contain one another: the one next to the triangle decides, as in reference_reaches)
-                for (uint32_t n = out.sleaf[sb.leaf_order[k]] & 0x7FFFFFFFu; n != kEndOfTree; n = out.ref_nested ? kEndOfTree : out.node_parent[n])
+                for (uint32_t n = first; n != kEndOfTree; n = out.ref_nested ? kEndOfTree : out.node_parent[n])
                     for (int a = 0; a < 3; a++) {
                         if (!(tb.hi[a] - tb.lo[a] < 1e-4)) continue;
                         const bool flat = tb.lo[a] == tb.hi[a];
                         if (!(tb.lo[a] - out.nodes[n].lo[a] >= 1e-5)) {
                             faces |= 1u << (2 * a);
-                            if (!(flat && out.nodes[n].lo[a] == tb.lo[a])) inexact |= 1u << (2 * a);
+                            if (!(flat && same[a] && out.nodes[n].lo[a] == tb.lo[a])) inexact |= 1u << (2 * a);
                         }
                         if (!(out.nodes[n].hi[a] - tb.hi[a] >= 1e-5)) {
                             faces |= 2u << (2 * a);
-                            if (!(flat && out.nodes[n].hi[a] == tb.hi[a])) inexact |= 2u << (2 * a);
+                            if (!(flat && same[a] && out.nodes[n].hi[a] == tb.hi[a])) inexact |= 2u << (2 * a);
                         }
                     }
+            };
+            const bool all_same[3] = {true, true, true};
+            if (thin_axes > 0) chain(out.sleaf[pos] & 0x7FFFFFFFu, own_box[pos], all_same);
+            if (ob >= 0) {
+                // An entry that belongs to an object: the chain runs through the mesh's boxes with the ray as the mesh sees
+                // it (above) and goes on through the world's boxes, from the node that holds the object, with the ray
+                // itself.  The kernels look at the ray as the mesh sees it: a bit found in the world's tree means the same
+                // there on an axis the object's transform leaves alone (every axis of an object that is only moved, y of one
+                // that is also turned), and the product that settles an exact tie is the same number in both trees when,
+                // in addition, the object is not moved along that axis (x - 0 = x) and the triangle's plane has the same
+                // coordinate in both.  Anything else: all bits, none exact - the reference's boxes are asked.
+                const CxObject& obj = out.objs[ob];
+                const Box3& wb = world_box[pos];
+                const Box3& tb = own_box[pos];
+                bool same[3], usable = true;
+                for (int a = 0; a < 3; a++) {
+                    const bool thin_w = wb.hi[a] - wb.lo[a] < 1e-4;
+                    const bool axis_kept = !(obj.flags & kCxRotate) || a == 1;
+                    if (thin_w && !axis_kept) usable = false;
+                    const bool unmoved = !(obj.flags & kCxTranslate) || obj.offset[a] == 0.0;
+                    same[a] = axis_kept && unmoved && tb.lo[a] == tb.hi[a] && wb.lo[a] == tb.lo[a] && wb.hi[a] == tb.hi[a];
+                }
+                if (!usable) { faces = 63u; inexact = 63u; }
+                else if (thin_world > 0) chain(out.obj_leaf[ob] & 0x7FFFFFFFu, wb, same);
             }
             // high word of the threshold, rounded up to a multiple of 4096; the face bits ride in the twelve bits below
             t.material = (int32_t)((((uint32_t)(bits >> 32) + 1u + 4095u) & ~4095u) | ((faces & ~inexact) << 6) | faces);

@@ -94,6 +94,7 @@ struct WfLaunchCfg {
     int stream_blocks;        // grid of the grid-stride kernels
     int redo_blocks;          // grid of k_redo (the rays of a launch that met an exact tie: few)
     bool lds_scene;
+    uint32_t n_entries;       // entries of the traversal hierarchy's triangle table (a scene with instances: (object, triangle) pairs)
     bool instanced;       // the scene holds instances: traversal and shading kernels with the ray transform in front of the triangle test
     bool ordered;         // the scene holds a constant_medium: rays are traced in the reference's own order (k_walk_ordered,
                           // k_conn_ordered) and the shading kernels know the isotropic phase function (implies `textured`)

@@ -325,8 +325,12 @@ template <class NodeT>
 struct TreeMem {
     const NodeT* wn;          // global or LDS copy
     const GpuTri* st;
+    const int32_t* entry_obj; // scenes with instances: SceneDev::xobj and SceneDev::objs (or their copies)
+    const CxObject* objs;
     BDPT_DEV NodeT wnode(int32_t i) const { return wn[i]; }
     BDPT_DEV GpuTri stri(uint32_t i) const { return st[i]; }
+    BDPT_DEV int32_t xobj(uint32_t i) const { return entry_obj[i]; }
+    BDPT_DEV CxObject object(int32_t k) const { return objs[k]; }
 };
 
 // Large scenes: the records nearest the root come from LDS, the deeper ones from global memory.
@@ -336,11 +340,15 @@ struct TopLdsMem {
     const NodeT* wn;
     const GpuTri* st;
     int32_t n_lds;
+    const int32_t* entry_obj;
+    const CxObject* objs;
     BDPT_DEV NodeT wnode(int32_t i) const {
         if (i < n_lds) return lds[i];
         return wn[i];
     }
     BDPT_DEV GpuTri stri(uint32_t i) const { return st[i]; }
+    BDPT_DEV int32_t xobj(uint32_t i) const { return entry_obj[i]; }
+    BDPT_DEV CxObject object(int32_t k) const { return objs[k]; }
 };
 
 // Box tests of the traversal hierarchy only have to be conservative, so they run in packed FP32 with
@@ -703,11 +711,11 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
                 const GpuTri tr = mem.stri(leaf_next);
                 V3 to = o, td = d;
                 if (INSTANCED) {
-                    const int32_t ob = sc.xobj[leaf_next];
+                    const int32_t ob = mem.xobj(leaf_next);
                     if (ob >= 0) {
                         if (ob != cached_ob) {
                             cached_o = o; cached_d = d;
-                            cx_to_object(sc.objs[ob], cached_o, cached_d);
+                            cx_to_object(mem.object(ob), cached_o, cached_d);
                             cached_ob = ob;
                         }
                         to = cached_o; td = cached_d;
@@ -858,8 +866,25 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb,
         if (LDS_SCENE) {
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_xnodes);
-            stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, sc.n_tris, l_nodes, l_tris);
-            TreeMem<GpuQuadNode> mem{l_nodes, l_tris};
+            // Entries of the hierarchy's triangle table: with instances there is one per (object, triangle) pair, and behind
+            // the table stand the objects (their transforms) and the object of every entry - the loads a triangle test waits for.
+            const uint32_t n_entries = !INSTANCED ? sc.n_tris
+                : (scene_lds_bytes - sc.n_xnodes * (uint32_t)sizeof(GpuQuadNode) - sc.n_objs * (uint32_t)sizeof(CxObject)) / (uint32_t)(sizeof(GpuTri) + sizeof(int32_t));
+            CxObject* l_objs = reinterpret_cast<CxObject*>(l_tris + n_entries);
+            int32_t* l_xobj = reinterpret_cast<int32_t*>(l_objs + (INSTANCED ? sc.n_objs : 0u));
+            if (INSTANCED) {
+                const uint4* src = reinterpret_cast<const uint4*>(sc.objs);
+                uint4* dst = reinterpret_cast<uint4*>(l_objs);
+                for (uint32_t k = threadIdx.x; k < sc.n_objs * (uint32_t)(sizeof(CxObject) / 16); k += blockDim.x) dst[k] = src[k];
+                for (uint32_t k = threadIdx.x; k < n_entries; k += blockDim.x) l_xobj[k] = sc.xobj[k];
+            }
+            stage_tree(sc.xnodes, sc.n_xnodes, sc.xtris, n_entries, l_nodes, l_tris);       // (ends with a barrier)
+            TreeMem<GpuQuadNode> mem{l_nodes, l_tris, l_xobj, l_objs};
+            if (INSTANCED) {        // (the reference's two-level tree stays in global memory: only ties ask for it)
+                const InstancedRefTree ref;
+                traverse_queue<SHADOW, STATS, true>(mem, ref, sc, wb, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
+                return;
+            }
             // (the copy of the reference's tree lies behind the stack part; only visibility rays consult it)
             if (SHADOW) {
                 const RefTree ref = stage_ref_tree(sc, smem + scene_lds_bytes + (size_t)(lds_stack + 1) * kBlock * sizeof(double));
@@ -872,7 +897,7 @@ __global__ __launch_bounds__(kBlock) void k_traverse(SceneDev sc, WfBuffers wb,
             GpuQuadNode* l_nodes = reinterpret_cast<GpuQuadNode*>(smem);
             const uint32_t n_top = sc.n_xnodes < top_nodes ? sc.n_xnodes : top_nodes;
             stage_tree(sc.xnodes, n_top, sc.xtris, 0u, l_nodes, (GpuTri*)nullptr);
-            TopLdsMem<GpuQuadNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top};
+            TopLdsMem<GpuQuadNode> mem{l_nodes, sc.xnodes, sc.xtris, (int32_t)n_top, sc.xobj, sc.objs};
             if (INSTANCED) {
                 const InstancedRefTree ref;
                 traverse_queue<SHADOW, STATS, true>(mem, ref, sc, wb, count, cursor, stats, refill_threshold, wave_chunk, leaf_threshold, leaf_inner, sc.coord_bound, l_stack, lds_stack, first_base, redo_list, redo_count);
@@ -1602,9 +1627,11 @@ BDPT_DEV Vertex staged_vertex(const double* lds, uint32_t budget, uint32_t idx) 
 // on a 0.96 M-triangle lattice: 2 361 -> 1 446 Msamples/s with the test): those scenes start the ray's walk at that
 // triangle instead (WfBuffers::shadow_first) and evaluate the few clear pairs when they are added.
 // TEX: the factors of a pair come from its vertices (Vertex::f), not from the material table.
-template <bool STATS, bool OWN_TEST, bool TEX>
+// INST (with OWN_TEST): a scene with instances.  A vertex names an entry of the leaf order, the test reads the entry's
+// record of the traversal hierarchy's table (triangle, thresholds, face bits) and takes the ray as the entry's object sees it.
+template <bool STATS, bool OWN_TEST, bool TEX, bool INST = false>
 __global__ __launch_bounds__(kBlock) void k_connect(SceneDev sc, GpuCamera cam, WfBuffers wb, uint32_t n_slots, int pass,
-                                                   uint32_t* shadow_count, uint32_t budget, uint32_t chunk, unsigned long long* stats) {
+                                                   uint32_t* shadow_count, uint32_t budget, uint32_t chunk, uint32_t n_entries, unsigned long long* stats) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ double s_pair_mats[kPairMats * 6];
     const uint32_t tile0 = wb.pass_bounds[pass], tile1 = wb.pass_bounds[pass + 1];
@@ -1616,7 +1643,24 @@ __global__ __launch_bounds__(kBlock) void k_connect(SceneDev sc, GpuCamera cam, 
     const GpuTri* own_tris = sc.tris;
     const int32_t* own_graze = sc.tri_graze;
     const uint32_t* own_leaf = sc.tri_leaf;
-    if (OWN_TEST) {         // small scene: the reference's tree and the triangle tables the test reads, in LDS behind the staging areas
+    const CxObject* own_objs = sc.objs;
+    const int32_t* own_xobj = sc.xobj;
+    const uint32_t* own_xpos = sc.tri_xpos;
+    if (OWN_TEST && INST) {     // the hierarchy's triangle table, the objects, and per entry its object and its place in that table
+        unsigned char* at0 = smem + (size_t)n_waves_block * budget * W * sizeof(double);
+        GpuTri* l_tris = reinterpret_cast<GpuTri*>(at0);
+        CxObject* l_objs = reinterpret_cast<CxObject*>(l_tris + n_entries);
+        int32_t* l_xobj = reinterpret_cast<int32_t*>(l_objs + sc.n_objs);
+        uint32_t* l_xpos = reinterpret_cast<uint32_t*>(l_xobj + n_entries);
+        const uint4* src = reinterpret_cast<const uint4*>(sc.xtris);
+        uint4* dst = reinterpret_cast<uint4*>(l_tris);
+        for (uint32_t k = threadIdx.x; k < n_entries * (uint32_t)(sizeof(GpuTri) / 16); k += blockDim.x) dst[k] = src[k];
+        src = reinterpret_cast<const uint4*>(sc.objs);
+        dst = reinterpret_cast<uint4*>(l_objs);
+        for (uint32_t k = threadIdx.x; k < sc.n_objs * (uint32_t)(sizeof(CxObject) / 16); k += blockDim.x) dst[k] = src[k];
+        for (uint32_t k = threadIdx.x; k < n_entries; k += blockDim.x) { l_xobj[k] = sc.xobj[k]; l_xpos[k] = sc.tri_xpos[k]; }
+        own_tris = l_tris; own_objs = l_objs; own_xobj = l_xobj; own_xpos = l_xpos;
+    } else if (OWN_TEST) {         // small scene: the reference's tree and the triangle tables the test reads, in LDS behind the staging areas
         unsigned char* at0 = smem + (size_t)n_waves_block * budget * W * sizeof(double);
         unsigned char* at = at0 + ((ref_tree_lds_bytes(sc.n_nodes) + 15) & ~(size_t)15);
         GpuTri* l_tris = reinterpret_cast<GpuTri*>(at);
@@ -1728,19 +1772,32 @@ __global__ __launch_bounds__(kBlock) void k_connect(SceneDev sc, GpuCamera cam, 
                                         emit = !(len2(f_cam) <= 0) && pair_geometry(cv, lv, g);                                // camera.h:458-460
                                         if (emit) { f_light = TEX ? lv.f : pmats.light_factor(sc, lv.info); emit = len2(f_light) > 0; }      // camera.h:462-469
                                         if (OWN_TEST && emit) {
-                                            GpuTri own = own_tris[lv.tri];
-                                            own.material = own_graze[lv.tri];
+                                            GpuTri own;
+                                            V3 to = g.origin, td = g.dir_unit;       // the ray as the triangle's own boxes see it
+                                            if (INST) {
+                                                const uint32_t x = own_xpos[lv.tri];
+                                                own = own_tris[x];
+                                                const int32_t ob = own_xobj[x];
+                                                if (ob >= 0) cx_to_object(own_objs[ob], to, td);
+                                            } else {
+                                                own = own_tris[lv.tri];
+                                                own.material = own_graze[lv.tri];
+                                            }
                                             double t, u, v, det;
-                                            if (tri_candidate(own, g.origin, g.dir_unit, 0.001, t, u, v, det) && t <= g.max_t) {
-                                                int ask = grazes(own, u, v, t, det, gbits) ? 2 : (nearly_equal(t, g.max_t) ? far_end_tie<true>(own, g.origin, g.dir_unit, g.max_t) : 0);
+                                            if (tri_candidate(own, to, td, 0.001, t, u, v, det) && t <= g.max_t) {
+                                                auto reaches = [&]() {
+                                                    if (INST) return instanced_reaches(sc, lv.tri, g.origin, g.dir_unit, g.max_t);
+                                                    return reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t);
+                                                };
+                                                int ask = grazes(own, u, v, t, det, gbits) ? 2 : (nearly_equal(t, g.max_t) ? far_end_tie<true>(own, to, td, g.max_t) : 0);
 #ifdef BDPT_TIE_CHECK
                                                 if (!grazes(own, u, v, t, det, gbits)) {
-                                                    const bool reached = reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t);
-                                                    tie_check_record(nearly_equal(t, g.max_t), own, g.origin, g.dir_unit, g.max_t, reached);
+                                                    const bool reached = reaches();
+                                                    tie_check_record(nearly_equal(t, g.max_t), own, to, td, g.max_t, reached);
                                                     ask = reached ? 0 : 1;
                                                 }
 #endif
-                                                if (ask == 2) ask = reference_reaches_inline(ref.nodes, ref.parents, sc.ref_nested != 0u, own_leaf[lv.tri], g.origin, g.dir_unit, g.max_t) ? 0 : 1;
+                                                if (ask == 2) ask = reaches() ? 0 : 1;
                                                 if (ask == 0) emit = false;
                                             }
                                         }
@@ -2137,6 +2194,8 @@ hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu) {
     if (cfg.conn_lds_bytes > ((size_t)64 << 10)) {      // more than 64 KiB of dynamic LDS has to be asked for
         const int bytes = (int)cfg.conn_lds_bytes;
         const void* fns[] = {reinterpret_cast<const void*>(k_connect<false, true, false>), reinterpret_cast<const void*>(k_connect<true, true, false>),
+                             reinterpret_cast<const void*>(k_connect<false, true, false, true>), reinterpret_cast<const void*>(k_connect<true, true, false, true>),
+                             reinterpret_cast<const void*>(k_connect<false, true, true, true>), reinterpret_cast<const void*>(k_connect<true, true, true, true>),
                              reinterpret_cast<const void*>(k_connect<false, false, true>), reinterpret_cast<const void*>(k_connect<true, false, true>),
                              reinterpret_cast<const void*>(k_connect<false, false, false>), reinterpret_cast<const void*>(k_connect<true, false, false>)};
         for (const void* fn : fns) {
@@ -2144,7 +2203,12 @@ hipError_t wf_prepare_traverse(const WfLaunchCfg& cfg, int* blocks_per_cu) {
             if (e != hipSuccess) return e;
         }
     }
-    if (cfg.instanced) {
+    if (cfg.instanced && cfg.lds_scene) {
+        e = prepare_traverse<false, false, true, true>(shm, blocks_per_cu);
+        if (e == hipSuccess) e = prepare_traverse<false, true, true, true>(shm, nullptr);
+        if (e == hipSuccess) e = prepare_traverse<true, false, true, true>(shm, nullptr);
+        if (e == hipSuccess) e = prepare_traverse<true, true, true, true>(shm, nullptr);
+    } else if (cfg.instanced) {
         e = prepare_traverse<false, false, false, true>(shm, blocks_per_cu);
         if (e == hipSuccess) e = prepare_traverse<false, true, false, true>(shm, nullptr);
         if (e == hipSuccess) e = prepare_traverse<true, false, false, true>(shm, nullptr);
@@ -2182,7 +2246,10 @@ template <bool SHADOW>
 static hipError_t launch_traverse(const SceneDev& sc, const WfBuffers& wb, const uint32_t* count_ptr,
                                   uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats,
                                   hipStream_t st, uint32_t* redo_list = nullptr, uint32_t* redo_count = nullptr) {
-    if (cfg.instanced) {
+    if (cfg.instanced && cfg.lds_scene) {
+        if (stats) launch_traverse_as<SHADOW, true, true, true>(sc, wb, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+        else launch_traverse_as<SHADOW, false, true, true>(sc, wb, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
+    } else if (cfg.instanced) {
         if (stats) launch_traverse_as<SHADOW, true, false, true>(sc, wb, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
         else launch_traverse_as<SHADOW, false, false, true>(sc, wb, count_ptr, count_imm, cursor, cfg, stats, st, redo_list, redo_count);
     } else if (stats) {
@@ -2311,16 +2378,24 @@ hipError_t wf_conn_plan(const WfBuffers& wb, uint32_t n_slots, const WfLaunchCfg
     return hipGetLastError();
 }
 
-template <bool STATS, bool OWN_TEST, bool TEX>
+template <bool STATS, bool OWN_TEST, bool TEX, bool INST = false>
 static void launch_connect(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, uint32_t n_slots, int pass, uint32_t* shadow_count,
                            const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    hipLaunchKernelGGL((k_connect<STATS, OWN_TEST, TEX>), dim3(cfg.conn_blocks), dim3(64u * cfg.conn_waves), cfg.conn_lds_bytes, st, sc, cam, wb, n_slots,
-                       pass, shadow_count, cfg.conn_rec_budget, cfg.conn_chunk, stats);
+    hipLaunchKernelGGL((k_connect<STATS, OWN_TEST, TEX, INST>), dim3(cfg.conn_blocks), dim3(64u * cfg.conn_waves), cfg.conn_lds_bytes, st, sc, cam, wb, n_slots,
+                       pass, shadow_count, cfg.conn_rec_budget, cfg.conn_chunk, cfg.n_entries, stats);
 }
 
 hipError_t wf_connect(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, uint32_t n_slots, int pass, uint32_t* shadow_count,
                       const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
-    if (cfg.own_test) {
+    if (cfg.own_test && cfg.instanced) {
+        if (cfg.textured) {
+            if (stats) launch_connect<true, true, true, true>(sc, cam, wb, n_slots, pass, shadow_count, cfg, stats, st);
+            else launch_connect<false, true, true, true>(sc, cam, wb, n_slots, pass, shadow_count, cfg, stats, st);
+        } else {
+            if (stats) launch_connect<true, true, false, true>(sc, cam, wb, n_slots, pass, shadow_count, cfg, stats, st);
+            else launch_connect<false, true, false, true>(sc, cam, wb, n_slots, pass, shadow_count, cfg, stats, st);
+        }
+    } else if (cfg.own_test) {
         if (stats) launch_connect<true, true, false>(sc, cam, wb, n_slots, pass, shadow_count, cfg, stats, st);
         else launch_connect<false, true, false>(sc, cam, wb, n_slots, pass, shadow_count, cfg, stats, st);
     } else if (cfg.textured) {

@@ -33,6 +33,7 @@ def cases(scenes, full):
         ("lattice1m", scenes.sphere_lattice(10, 192 * k, 16, 10)),               # curved geometry over a flat floor
         ("cx_instances", composite_scene(scenes, "cx_instances")[0]),            # rotated / translated boxes (two-level boxes)
         ("lattice_instanced", scenes.sphere_lattice_instanced(6, 96 * k, 16, 10)),
+        ("cornell_instances", scenes.cornell_instances(96 * k, 64, 10)),         # turned and moved boxes whose tops lie in a box face of both trees
     ]
 
 
