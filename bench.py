@@ -254,7 +254,8 @@ def issue_summary(k):
 def kernel_class(name):
     if "k_traverse" in name:
         return "k_traverse"
-    for k in ("k_shade", "k_gen_eye", "k_gen_light", "k_conn_gen", "k_conn_accum", "k_conn_prepare", "k_resolve", "k_redo", "render_kernel"):
+    for k in ("k_shade", "k_gen_eye", "k_gen_light", "k_connect", "k_conn_add", "k_conn_count", "k_conn_plan", "k_conn_ordered", "k_walk_ordered",
+              "k_resolve", "k_redo", "render_kernel"):
         if k in name:
             return k
     return "other"

@@ -309,6 +309,7 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     if (!cfg.lds_scene) cfg.lds_bytes = 0;
     cfg.instanced = scene->dev.objs != nullptr;
     cfg.textured = scene->dev.tex != nullptr;
+    cfg.tex_pass = cfg.textured && scene->cx_host.textured;
     cfg.ordered = scene->ordered;
     if (cfg.ordered) { cfg.lds_scene = false; cfg.lds_bytes = 0; }        // (a scene with media has no such hierarchy)
     // (a scene with instances keeps the reference's two-level tree in global memory)
@@ -422,7 +423,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     const double cap_per_slot = !conn_queue ? 0.0 : (double)d1 * kn.conn_cap_tenths / 10.0;
     // bytes of state per sample slot
     // (ray, throughput and stream position twice: by entry of the live queue and of the next one)
-    const size_t per_slot = sizeof(double) * (2 * 6 + 2 * 3 + 1 + 3) + sizeof(uint32_t) * (5 + 2) + (scene->ordered ? 4 : 0) + vslots * rec_doubles * sizeof(double) +
+    const size_t per_slot = sizeof(double) * (2 * 6 + 2 * 3 + 1 + 3) + sizeof(uint32_t) * (5 + 2) + (scene->ordered ? 4 : 0) + (cfg.tex_pass ? 3 * sizeof(double) : 0) + vslots * rec_doubles * sizeof(double) +
                             (conn_queue ? 8 + 1 : 0) +
                             // the queue: a third more than what a pass may be given (pieces partly lost), a quarter more for
                             // the pieces the waves leave unused at the end (conn_blocks below is limited accordingly)
@@ -515,7 +516,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
     auto take = [&off](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
     const size_t o_ray = take(ns * 6 * 8), o_ray2 = take(ns * 6 * 8), o_thr = take(ns * 3 * 8), o_thr2 = take(ns * 3 * 8), o_hit = take(ns * 8), o_res = take(ns * 3 * 8);
     const size_t o_tri = take(ns * 4), o_ctr = take(ns * 4), o_cq1 = take(ns * 4), o_cq2 = take(ns * 4), o_cnt = take(ns * 4);
-    const size_t o_q0 = take(ns * 4), o_q1 = take(ns * 4), o_cq = take(scene->ordered ? ns * 4 : 0);
+    const size_t o_q0 = take(ns * 4), o_q1 = take(ns * 4), o_cq = take(scene->ordered ? ns * 4 : 0), o_tex = take(cfg.tex_pass ? ns * 3 * 8 : 0);
     const uint64_t ns_grouped = (ns + kVtxGroup - 1) / kVtxGroup * kVtxGroup;      // whole groups of slots
     const size_t o_vtx = take(ns_grouped * vslots * rec_doubles * 8), o_sh = take(shadow_cap * 7 * 8), o_shvis = take(shadow_cap);
     const size_t o_contrib = take(cfg.own_test ? shadow_cap * 3 * 8 : 0), o_pair = take(conn_queue && !cfg.own_test ? shadow_cap * 4 : 0);
@@ -577,6 +578,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
         wb.counts = reinterpret_cast<uint32_t*>(base + o_cnt);
         wb.queue[0] = reinterpret_cast<uint32_t*>(base + o_q0); wb.queue[1] = reinterpret_cast<uint32_t*>(base + o_q1);
         wb.conn_queue = reinterpret_cast<uint32_t*>(base + o_cq);
+        wb.tex_rgb = cfg.tex_pass ? reinterpret_cast<double*>(base + o_tex) : nullptr;
         wb.vtx = reinterpret_cast<double*>(base + o_vtx);
         wb.contrib = cfg.own_test ? reinterpret_cast<double*>(base + o_contrib) : nullptr;
         wb.shadow = reinterpret_cast<double*>(base + o_sh); wb.counters = reinterpret_cast<uint32_t*>(base + o_counters);
@@ -674,6 +676,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
             { int rc = timed(0, st, [&] { return cfg.ordered ? wf_walk_ordered(scene->dev, gcam, w, b, q_in, c_in, n_slots, cfg, st)
                                                              : wf_extend(scene->dev, w, c_in, n_slots, eye_cursor(k), cfg, stats, st, wb.queue[nxt], eye_redo(k)); }); if (rc != BDPT_OK) return rc; }
             if (!cfg.ordered) HIP_TRY(wf_redo(scene->dev, w, cfg, st, wb.queue[nxt], eye_redo(k)));
+            if (cfg.tex_pass) HIP_TRY(wf_tex_eval(scene->dev, gcam, w, b, q_in, c_in, n_slots, cfg, st));
             HIP_TRY(wf_shade(scene->dev, gcam, w, b, true, q_in, c_in, n_slots, wb.queue[nxt], eye_count(k), k == depth - 1, connections, keep_draws, cfg,
                              stats, st));
             cur = nxt;
@@ -688,6 +691,7 @@ int render_wavefront(bdpt_context* ctx, const bdpt_scene* scene, const bdpt_came
                 { int rc = timed(0, st, [&] { return cfg.ordered ? wf_walk_ordered(scene->dev, gcam, w, b, wb.queue[cur], light_count(k), 0, cfg, st)
                                                                  : wf_extend(scene->dev, w, light_count(k), 0, light_cursor(k), cfg, stats, st, wb.queue[cur ^ 1], light_redo(k)); }); if (rc != BDPT_OK) return rc; }
                 if (!cfg.ordered) HIP_TRY(wf_redo(scene->dev, w, cfg, st, wb.queue[cur ^ 1], light_redo(k)));
+                if (cfg.tex_pass) HIP_TRY(wf_tex_eval(scene->dev, gcam, w, b, wb.queue[cur], light_count(k), 0, cfg, st));
                 HIP_TRY(wf_shade(scene->dev, gcam, w, b, false, wb.queue[cur], light_count(k), 0, wb.queue[cur ^ 1],
                                  light_count(k + 1), k == depth - 2, true, keep_draws, cfg, stats, st));
                 cur ^= 1;

@@ -39,6 +39,7 @@ struct WfBuffers {
     // visibility ray are queue entries; the entries of ONE sample are contiguous and in the reference's pair order (a
     // outer, b inner), so the sample's sum is formed by walking them.
     double* shadow;       // [7][shadow_cap]  shadow rays: origin, direction, max_t (negative: an unused entry)
+    double* tex_rgb;      // [3][ns] by queue entry: value of the hit material's texture (k_tex_eval -> k_shade); null without textures
     uint8_t* sh_vis;      // [shadow_cap]  1: the entry's shadow ray came back clear (cleared when the entry is made)
     uint32_t* sh_pair;    // [shadow_cap]  a << 12 | b of the entry's pair
     uint32_t* shadow_first;   // [shadow_cap]  position in SceneDev::xtris of the triangle a shadow ray's walk tests first (the
@@ -98,6 +99,7 @@ struct WfLaunchCfg {
     bool instanced;       // the scene holds instances: traversal and shading kernels with the ray transform in front of the triangle test
     bool ordered;         // the scene holds a constant_medium: rays are traced in the reference's own order (k_walk_ordered,
                           // k_conn_ordered) and the shading kernels know the isotropic phase function (implies `textured`)
+    bool tex_pass;        // some material really carries a texture: k_tex_eval runs in front of every k_shade
     bool textured;        // some material carries a texture (implies `instanced`: those kernels, with vertex records of kVtxDoublesTextured words)
     // connection stage: k_connect stages the vertex records of a run of samples in LDS (conn_rec_budget records per wave)
     // and takes the shadow queue conn_chunk entries at a time; every wave may leave one such piece partly unused
@@ -131,6 +133,9 @@ hipError_t wf_extend(const SceneDev& sc, const WfBuffers& wb, const uint32_t* co
                      uint32_t count_imm, uint32_t* cursor, const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st,
                      uint32_t* redo_list, uint32_t* redo_count);
 hipError_t wf_redo(const SceneDev& sc, const WfBuffers& wb, const WfLaunchCfg& cfg, hipStream_t st, uint32_t* redo_list, uint32_t* redo_count);
+// values of the textures at the hits of the entries of a queue (before wf_shade reads them)
+hipError_t wf_tex_eval(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const uint32_t* queue_in,
+                       const uint32_t* count_in_ptr, uint32_t count_in_imm, const WfLaunchCfg& cfg, hipStream_t st);
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
                     const uint32_t* queue_in, const uint32_t* count_in_ptr, uint32_t count_in_imm, uint32_t* queue_out,
                     uint32_t* count_out, bool last_bounce, bool store_vertices, bool keep_draw_counts, const WfLaunchCfg& cfg,

@@ -1128,6 +1128,76 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_ordered(SceneDev sc, GpuCa
     }
 }
 
+// ------------------------------------------------------------------ texture values of one bounce
+// texture::value(u, v, p) (texture.h) of the hits whose material carries a texture, as a pass of its own in front of
+// k_shade: a workgroup takes a tile of the queue, collects the entries with such a hit in LDS - those whose texture is a
+// noise_texture (perlin::turb, seven octaves of eight corners each: long, and hungry for registers) from the front of the
+// list, the others from its back - and evaluates the list densely, one entry per lane.  Inside k_shade the same call cost
+// every wave the whole evaluation for the handful of its lanes that stand on a textured surface, and its registers
+// (217 against 118) cost the kernel half of its waves.  The value goes to WfBuffers::tex_rgb, by queue entry.
+template <bool MEDIA>
+__global__ __launch_bounds__(kStageBlock) void k_tex_eval(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue_in,
+                                                           const uint32_t* count_in_ptr, uint32_t count_in_imm) {
+    __shared__ uint32_t s_list[kStageTile];
+    __shared__ uint32_t s_front, s_back;
+    const uint32_t count = count_in_ptr ? *count_in_ptr : count_in_imm;
+    const uint64_t ns = wb.ns;
+    for (uint32_t tile = blockIdx.x * kStageTile; tile < count; tile += gridDim.x * kStageTile) {
+        if (threadIdx.x == 0) { s_front = 0u; s_back = 0u; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kStagePerThread; j++) {
+            const uint32_t k = tile + (uint32_t)j * kStageBlock + threadIdx.x;
+            if (k >= count) continue;
+            const uint32_t slot = queue_in ? queue_in[k] : k;
+            int pi, pj, ps;
+            if (slot == kDeadSlot || !slot_to_sample(cam, b, slot, pi, pj, ps)) continue;
+            const int32_t pos = wb.hit_tri[k];
+            int32_t mat_id = -1;
+            if (MEDIA && pos <= kHitMedium0) mat_id = sc.objs[kHitMedium0 - pos].phase_material;
+            else if (pos >= 0) mat_id = (int32_t)(sc.shade[pos].mat & kVtxMatMask);
+            if (mat_id < 0) continue;
+            const int32_t tex1 = sc.mats[mat_id].pad;
+            if (tex1 <= 0) continue;
+            if (sc.tex[tex1 - 1].type == BDPT_TEX_NOISE) s_list[atomicAdd(&s_front, 1u)] = k;
+            else s_list[kStageTile - 1u - atomicAdd(&s_back, 1u)] = k;
+        }
+        __syncthreads();
+        const uint32_t n_front = s_front, n_all = s_front + s_back;
+        for (uint32_t i = threadIdx.x; i < n_all; i += kStageBlock) {
+            const uint32_t k = (i < n_front) ? s_list[i] : s_list[kStageTile - 1u - (i - n_front)];
+            const int32_t pos = wb.hit_tri[k];
+            const double t_hit = wb.hit[k];
+            const V3 o = mk(wb.ray[k], wb.ray[ns + k], wb.ray[2 * ns + k]);
+            const V3 d = mk(wb.ray[3 * ns + k], wb.ray[4 * ns + k], wb.ray[5 * ns + k]);
+            V3 value;
+            if (MEDIA && pos <= kHitMedium0) {                                   // constant_medium.h:45-50: u = v = 0
+                const int32_t mat_id = sc.objs[kHitMedium0 - pos].phase_material;
+                value = cx_texture(sc, sc.mats[mat_id].pad - 1, 0.0, 0.0, add(o, scl(t_hit, d)));
+            } else {
+                // the hit_record as k_shade forms it: the point through the object's wrappers, (u, v) by the operations of the
+                // triangle test that found the hit
+                const GpuShadeRec r = sc.shade[pos];
+                const int32_t ob = sc.pos_obj[pos];
+                V3 p, normal;
+                bool front_face;
+                V3 to = o, td = d;
+                if (ob >= 0) {
+                    instanced_surface(sc, ob, ld3(r.normal), o, d, t_hit, p, normal, front_face);
+                    cx_to_object(sc.objs[ob], to, td);
+                } else {
+                    p = add(o, scl(t_hit, d));
+                }
+                double t, u, v, det;
+                (void)tri_candidate(sc.tris[r.tri], to, td, 0.001, t, u, v, det);
+                value = cx_texture(sc, sc.mats[r.mat & kVtxMatMask].pad - 1, u, v, p);
+            }
+            wb.tex_rgb[k] = value.x; wb.tex_rgb[ns + k] = value.y; wb.tex_rgb[2 * ns + k] = value.z;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ shading of one bounce
 // TEX (with INSTANCED): materials may carry a texture.  Its value at the hit (texture::value(u, v, p), material.h:45,135)
 // takes the place of the material's solid colour, and the vertex record keeps the colour the vertex can contribute
@@ -1216,7 +1286,7 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
                 ShadeMat m;
                 m.normal = mk(1, 0, 0); m.rgb = ld3(gm.rgb); m.fuzz = gm.fuzz; m.ior = gm.ior; m.type = gm.type; m.id = mat_id;
                 const V3 p = add(o, scl(t_hit, d));
-                if (gm.pad > 0) m.rgb = cx_texture(sc, gm.pad - 1, 0.0, 0.0, p);
+                if (gm.pad > 0) m.rgb = mk(wb.tex_rgb[k], wb.tex_rgb[ns + k], wb.tex_rgb[2 * ns + k]);      // (k_tex_eval)
                 shade_surface<EYE, LAMBERT, MEDIA>(m, 0, p, mk(1, 0, 0), true, d, T, rng, bo);
                 bo.vx.f = (m.type == 4) ? divs(m.rgb, 4 * kPi) : mk(0, 0, 0);
             } else if (INSTANCED) {
@@ -1237,16 +1307,8 @@ __global__ __launch_bounds__(kStageBlock) void k_shade(SceneDev sc, GpuCamera ca
                 }
                 // (the vertex of such a scene names its entry of `stris`, not its triangle: SceneDev::tri_xpos)
                 const int32_t vertex_tri = (int32_t)pos;
-                if (TEX) {
-                    const int32_t tex1 = sc.mats[m.id].pad;
-                    if (tex1 > 0) {
-                        V3 to = o, td = d;
-                        if (ob >= 0) cx_to_object(sc.objs[ob], to, td);
-                        double t, u, v, det;
-                        (void)tri_candidate(sc.tris[r.tri], to, td, 0.001, t, u, v, det);
-                        m.rgb = cx_texture(sc, tex1 - 1, u, v, p);
-                    }
-                }
+                // (the value of the material's texture at the hit: k_tex_eval has left it with the queue entry)
+                if (TEX && sc.mats[m.id].pad > 0) m.rgb = mk(wb.tex_rgb[k], wb.tex_rgb[ns + k], wb.tex_rgb[2 * ns + k]);
                 shade_surface<EYE, LAMBERT, MEDIA>(m, vertex_tri, p, normal, front_face, d, T, rng, bo);
                 if (TEX) bo.vx.f = (m.type == 3) ? (front_face ? m.rgb : mk(0, 0, 0)) : ((m.type == 0) ? divs(m.rgb, kPi) : mk(0, 0, 0));
             } else {
@@ -2293,6 +2355,14 @@ hipError_t wf_conn_ordered(const SceneDev& sc, const GpuCamera& cam, const WfBuf
 hipError_t wf_occlude(const SceneDev& sc, const WfBuffers& wb, const uint32_t* shadow_count, uint32_t count_imm, uint32_t* cursor,
                       const WfLaunchCfg& cfg, unsigned long long* stats, hipStream_t st) {
     return launch_traverse<true>(sc, wb, shadow_count, count_imm, cursor, cfg, stats, st);
+}
+
+hipError_t wf_tex_eval(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const uint32_t* queue_in,
+                       const uint32_t* count_in_ptr, uint32_t count_in_imm, const WfLaunchCfg& cfg, hipStream_t st) {
+    dim3 grid(cfg.stream_blocks), block(kStageBlock);
+    if (cfg.ordered) hipLaunchKernelGGL((k_tex_eval<true>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm);
+    else hipLaunchKernelGGL((k_tex_eval<false>), grid, block, 0, st, sc, cam, wb, b, queue_in, count_in_ptr, count_in_imm);
+    return hipGetLastError();
 }
 
 hipError_t wf_shade(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, bool eye,
