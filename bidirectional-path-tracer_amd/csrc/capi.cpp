@@ -310,6 +310,10 @@ int make_launch_cfg(const bdpt_context* ctx, const bdpt_scene* scene, WfLaunchCf
     cfg.instanced = scene->dev.objs != nullptr;
     cfg.textured = scene->dev.tex != nullptr;
     cfg.tex_pass = cfg.textured && scene->cx_host.textured;
+    {
+        const size_t walk_bytes = (size_t)scene->dev.n_nodes * sizeof(GpuNode) + (size_t)scene->dev.n_tris * sizeof(GpuTri) + (size_t)scene->dev.n_objs * sizeof(CxObject);
+        cfg.walk_lds_bytes = (scene->ordered && walk_bytes <= ((size_t)24 << 10) && !kn.no_lds_scene) ? walk_bytes : 0;
+    }
     cfg.ordered = scene->ordered;
     if (cfg.ordered) { cfg.lds_scene = false; cfg.lds_bytes = 0; }        // (a scene with media has no such hierarchy)
     // (a scene with instances keeps the reference's two-level tree in global memory)

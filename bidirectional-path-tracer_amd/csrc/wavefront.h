@@ -99,6 +99,7 @@ struct WfLaunchCfg {
     bool instanced;       // the scene holds instances: traversal and shading kernels with the ray transform in front of the triangle test
     bool ordered;         // the scene holds a constant_medium: rays are traced in the reference's own order (k_walk_ordered,
                           // k_conn_ordered) and the shading kernels know the isotropic phase function (implies `textured`)
+    size_t walk_lds_bytes;    // a scene with media whose tables the ordered walks copy into LDS first: their size (0: read from global memory)
     bool tex_pass;        // some material really carries a texture: k_tex_eval runs in front of every k_shade
     bool textured;        // some material carries a texture (implies `instanced`: those kernels, with vertex records of kVtxDoublesTextured words)
     // connection stage: k_connect stages the vertex records of a run of samples in LDS (conn_rec_budget records per wave)

@@ -1005,10 +1005,37 @@ __global__ __launch_bounds__(kBlock) void k_redo(SceneDev sc, WfBuffers wb, cons
 // the rays of such a scene are traced over the reference's own two-level tree in the reference's order, one ray per
 // lane, the sample's stream position read and written back.  Result codes as k_traverse writes them, plus the codes
 // <= kHitMedium0 of a hit inside a medium.
+// LDS: the tables the walk reads (the two-level tree, the triangles, the objects) are small enough to be copied into LDS by
+// every workgroup first: the walk is a chain of dependent fetches, one ray per lane.
+struct StagedWalkScene {
+    const GpuNode* nodes;
+    const GpuTri* tris;
+    const CxObject* objs;
+};
+BDPT_DEV size_t staged_walk_bytes(uint32_t n_nodes, uint32_t n_tris, uint32_t n_objs) {
+    return (size_t)n_nodes * sizeof(GpuNode) + (size_t)n_tris * sizeof(GpuTri) + (size_t)n_objs * sizeof(CxObject);
+}
+// all threads of the workgroup; `dst` 16-byte aligned; ends with a barrier
+BDPT_DEV StagedWalkScene stage_walk_scene(const SceneDev& sc, unsigned char* dst) {
+    GpuNode* l_nodes = reinterpret_cast<GpuNode*>(dst);
+    GpuTri* l_tris = reinterpret_cast<GpuTri*>(l_nodes + sc.n_nodes);
+    CxObject* l_objs = reinterpret_cast<CxObject*>(l_tris + sc.n_tris);
+    const uint32_t n16 = (uint32_t)(staged_walk_bytes(sc.n_nodes, sc.n_tris, sc.n_objs) / 16);
+    const uint32_t a16 = sc.n_nodes * (uint32_t)(sizeof(GpuNode) / 16), b16 = a16 + sc.n_tris * (uint32_t)(sizeof(GpuTri) / 16);
+    uint4* out = reinterpret_cast<uint4*>(dst);
+    for (uint32_t k = threadIdx.x; k < n16; k += blockDim.x)
+        out[k] = k < a16 ? reinterpret_cast<const uint4*>(sc.nodes)[k] : (k < b16 ? reinterpret_cast<const uint4*>(sc.tris)[k - a16] : reinterpret_cast<const uint4*>(sc.objs)[k - b16]);
+    __syncthreads();
+    return StagedWalkScene{l_nodes, l_tris, l_objs};
+}
+template <bool LDS>
 __global__ __launch_bounds__(kBlock) void k_walk_ordered(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* queue,
                                                          const uint32_t* count_ptr, uint32_t count_imm) {
+    extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
     const uint64_t ns = wb.ns;
+    StagedWalkScene staged = {nullptr, nullptr, nullptr};
+    if (LDS) staged = stage_walk_scene(sc, smem);
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
         const uint32_t slot = queue ? queue[k] : k;
         int pi, pj, ps;
@@ -1020,7 +1047,7 @@ __global__ __launch_bounds__(kBlock) void k_walk_ordered(SceneDev sc, GpuCamera 
         Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         CxHit h;
         int32_t code = -1;
-        if (cx_walk<kStatsOff>(sc, o, d, 0.001, kInf, h, c, rng)) {
+        if (LDS ? cx_walk<kStatsOff>(staged, o, d, 0.001, kInf, h, c, rng) : cx_walk<kStatsOff>(sc, o, d, 0.001, kInf, h, c, rng)) {
             code = (h.tri < 0) ? kHitMedium0 - h.obj : (int32_t)((h.obj >= 0 ? sc.obj_pos0[h.obj] : 0u) + sc.tri_pos[h.tri]);
             wb.hit[k] = h.t;
         }
@@ -1038,7 +1065,11 @@ __global__ __launch_bounds__(kBlock) void k_walk_ordered(SceneDev sc, GpuCamera 
 // between the rounds.  (One sample per lane with a loop over its pairs: a wave then takes as long as its longest
 // sample, twice as long in a Cornell box with smoke.)
 constexpr uint32_t kOrderedMaxPairs = 1024;       // histogram size: samples with more pairs share the last bin
+template <bool LDS>
 __global__ __launch_bounds__(kStageBlock) void k_conn_ordered(SceneDev sc, GpuCamera cam, WfBuffers wb, WfBatch b, const uint32_t* conn_count) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    StagedWalkScene staged = {nullptr, nullptr, nullptr};
+    if (LDS) staged = stage_walk_scene(sc, smem);
     __shared__ uint32_t s_slot[kStageTile], s_cnt[kStageTile], s_ctr[kStageTile];
     __shared__ unsigned long long s_key[kStageTile];
     __shared__ double s_res[3][kStageTile];
@@ -1109,7 +1140,8 @@ __global__ __launch_bounds__(kStageBlock) void k_conn_ordered(SceneDev sc, GpuCa
                     rng.counter = s_ctr[el];
                     Counters c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
                     CxHit tmp;
-                    const bool blocked = cx_walk<kStatsOff>(sc, g.origin, g.dir_unit, 0.001, g.max_t, tmp, c, rng);
+                    const bool blocked = LDS ? cx_walk<kStatsOff>(staged, g.origin, g.dir_unit, 0.001, g.max_t, tmp, c, rng)
+                                             : cx_walk<kStatsOff>(sc, g.origin, g.dir_unit, 0.001, g.max_t, tmp, c, rng);
                     s_ctr[el] = rng.counter;
                     if (!blocked) {
                         const V3 f_cam = (cv.info & kVtxIsLight) ? mk(0, 0, 0) : cv.f;     // material.h:35-37
@@ -2342,13 +2374,15 @@ hipError_t wf_redo(const SceneDev& sc, const WfBuffers& wb, const WfLaunchCfg& c
 
 hipError_t wf_walk_ordered(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const uint32_t* queue,
                            const uint32_t* count_ptr, uint32_t count_imm, const WfLaunchCfg& cfg, hipStream_t st) {
-    hipLaunchKernelGGL(k_walk_ordered, dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, b, queue, count_ptr, count_imm);
+    if (cfg.walk_lds_bytes) hipLaunchKernelGGL(k_walk_ordered<true>, dim3(cfg.stream_blocks), dim3(kBlock), cfg.walk_lds_bytes, st, sc, cam, wb, b, queue, count_ptr, count_imm);
+    else hipLaunchKernelGGL(k_walk_ordered<false>, dim3(cfg.stream_blocks), dim3(kBlock), 0, st, sc, cam, wb, b, queue, count_ptr, count_imm);
     return hipGetLastError();
 }
 
 hipError_t wf_conn_ordered(const SceneDev& sc, const GpuCamera& cam, const WfBuffers& wb, const WfBatch& b, const uint32_t* conn_count,
                            const WfLaunchCfg& cfg, hipStream_t st) {
-    hipLaunchKernelGGL(k_conn_ordered, dim3(cfg.stream_blocks), dim3(kStageBlock), 0, st, sc, cam, wb, b, conn_count);
+    if (cfg.walk_lds_bytes) hipLaunchKernelGGL(k_conn_ordered<true>, dim3(cfg.stream_blocks), dim3(kStageBlock), cfg.walk_lds_bytes, st, sc, cam, wb, b, conn_count);
+    else hipLaunchKernelGGL(k_conn_ordered<false>, dim3(cfg.stream_blocks), dim3(kStageBlock), 0, st, sc, cam, wb, b, conn_count);
     return hipGetLastError();
 }
 
