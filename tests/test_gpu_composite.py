@@ -132,6 +132,33 @@ def test_composite_scenes_render_on_the_pipeline(case):
     assert_bit_equal(sc.render(cam, seed=seed, megakernel=True), g["framebuffer"], name + ": single kernel")
 
 
+CX_SETTINGS = [
+    {"BDPT_WF_NO_LDS_SCENE": "1"},                                 # tables in global memory (what a large scene runs)
+    {"BDPT_WF_NO_OWN_TEST": "1"},                                  # the far end's own triangle left to the traversal
+    {"BDPT_WF_NO_OWN_TEST": "1", "BDPT_WF_NO_FIRST_LEAF": "1"},
+    {"BDPT_WF_BATCH_LOG2": "10", "BDPT_WF_STREAMS": "2", "BDPT_WF_CONN_CAP": "5"},
+]
+
+
+@pytest.mark.parametrize("name", sorted(COMPOSITE_CASES))
+def test_composite_image_does_not_depend_on_launch_settings(scenes, name, monkeypatch):
+    """Small scenes with instances, textures or media have their tables staged in LDS and their far-end ties settled by
+    the connection kernel; larger ones read global memory and leave the ties to the traversal.  Every combination returns
+    the reference's framebuffer."""
+    flat, g = composite_scene(scenes, name)
+    cam = capi.camera_initialize(flat.camera)
+    seed = int(g["render_seed"][0])
+    for setting in CX_SETTINGS:
+        with monkeypatch.context() as m:
+            for k, v in setting.items():
+                m.setenv(k, v)
+            c2 = capi.Context(0)              # the settings are read when a context is created
+            sc2 = c2.scene(flat)
+            assert_bit_equal(sc2.render(cam, seed=seed), g["framebuffer"], "%s %s" % (name, setting))
+            sc2.close()
+            c2.close()
+
+
 def test_visibility_matches_reference(case):
     name, flat, sc, g = case
     vis = sc.visible(g["pairs"])

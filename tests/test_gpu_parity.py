@@ -506,6 +506,7 @@ WF_SETTINGS = [
     {"BDPT_WF_CONN_BUDGET": "512", "BDPT_WF_CONN_CAP": "40"},
     {"BDPT_WF_REDO_BLOCKS": "7"},
     {"BDPT_WF_SORT_CELLS": "64"}, {"BDPT_WF_SORT_CELLS": "5", "BDPT_WF_PIXEL_MAJOR": "0"}, {"BDPT_WF_SORT_CELLS": "0"},
+    {"BDPT_WF_NO_LDS_SCENE": "1"}, {"BDPT_WF_NO_OWN_TEST": "1"},  # a small scene on the kernels of a large one
 ]
 
 
