@@ -228,6 +228,7 @@ PMC_PASSES = [("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("l2", ["TCP
               ("issue", ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
                          "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"])]
 N_SIMD = 256 * 4             # compute units x SIMDs
+ENGINE_CLOCK_MHZ = 2400.0     # maximum engine clock of the MI355X; under load the chip runs below it
 N_XCD = 8
 
 
@@ -613,6 +614,19 @@ def main():
                  "frac": (frame_hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if frame_hbm else None,
                  "l2_request_bytes": frame_l2, "l2_frac_of_peak": (frame_l2 / (ms * 1e-3) / 1e9 / L2_PEAK_GBS) if frame_l2 else None,
                  "rays_per_s": rays_per_s}
+        if kernels and all("SQ_ACTIVE_INST_VALU" in k for k in kernels.values()):
+            # The binding resource of the frame: cycles in which a SIMD issues a VALU instruction, summed over all kernels
+            # of the frame (counter pass, kernels one after the other), against the cycles the overlapped frame takes at the
+            # nominal engine clock (a lower real clock makes the share larger).
+            clock_hz = ENGINE_CLOCK_MHZ * 1e6
+            valu_cycles = sum(k["SQ_ACTIVE_INST_VALU"] for k in kernels.values()) * 4.0 / N_SIMD
+            thread_cycles = sum(k.get("SQ_THREAD_CYCLES_VALU", 0.0) for k in kernels.values())
+            frame["valu"] = {"valu_issue_cycles_per_simd": valu_cycles, "engine_clock_mhz": clock_hz / 1e6,
+                             "frac_of_frame": valu_cycles / (ms * 1e-3 * clock_hz),
+                             "lanes_active": thread_cycles / (sum(k["SQ_ACTIVE_INST_VALU"] for k in kernels.values()) * 64.0),
+                             "by_kernel": {n: k["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMD / (ms * 1e-3 * clock_hz) for n, k in kernels.items()},
+                             "what": "share of the frame's cycles in which a SIMD issues a vector ALU instruction (FP64 triangle tests, packed-FP32 "
+                                     "box tests, shading), all kernels of the frame together: the resource this pipeline is closest to"}
         if args.megakernel:
             out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                                "kernel": frame["kernel"], "kernel_ms": ms, "algorithmic_bytes_per_launch": alg,
