@@ -594,11 +594,18 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
     int32_t cached_ob = -1;
     V3 cached_o = mk(0, 0, 0), cached_d = mk(0, 0, 0);
     uint32_t n_records = 0, n_box_hits = 0, n_tri = 0, n_tri_hits = 0, n_rays = 0;
+#ifdef BDPT_AB_PHASE_STATS
+    // measuring build: lane slots and active lanes of the two kinds of iteration, reported in place of the box / triangle counters
+    uint32_t ph_node_slots = 0, ph_node_lanes = 0, ph_leaf_slots = 0, ph_leaf_lanes = 0, ph_iters = 0;
+#endif
 #ifdef BDPT_AB_COUNT_REDO
     uint32_t n_redo = 0;
 #endif
 
     for (;;) {
+#ifdef BDPT_AB_PHASE_STATS
+        if (STATS) ph_iters++;
+#endif
         const unsigned long long idle = __ballot(!has);
         const int n_idle = __builtin_popcountll(idle);
         if (!exhausted && (n_idle >= kRefillThreshold)) {
@@ -669,6 +676,9 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
         const unsigned long long at_leaf = __ballot(has && leaf_left > 0);
         const bool leaf_phase = (at_leaf == active) || (__builtin_popcountll(at_leaf) >= kLeafThreshold);
         bool pop = false, done = false;
+#ifdef BDPT_AB_PHASE_STATS
+        if (STATS && !leaf_phase) { ph_node_slots++; if (has && leaf_left == 0) ph_node_lanes++; }
+#endif
         if (!leaf_phase) {
             if (has && leaf_left == 0) {
                 const auto nd = mem.wnode(cur);
@@ -707,6 +717,9 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
             }
         } else {
           for (;;) {
+#ifdef BDPT_AB_PHASE_STATS
+            if (STATS) { ph_leaf_slots++; if (has && leaf_left > 0 && !done) ph_leaf_lanes++; }
+#endif
             if (has && leaf_left > 0 && !done) {
                 const GpuTri tr = mem.stri(leaf_next);
                 V3 to = o, td = d;
@@ -796,6 +809,17 @@ BDPT_DEV void traverse_queue(const Mem& mem, const Ref& ref, const SceneDev& sc,
             has = false;
         }
     }
+#ifdef BDPT_AB_PHASE_STATS
+    if (STATS) {
+        flush_wave_counter(&stats[SHADOW ? 6 : 0], n_rays);
+        flush_wave_counter(&stats[1], ph_node_slots);
+        flush_wave_counter(&stats[2], ph_node_lanes);
+        flush_wave_counter(&stats[3], ph_iters);
+        flush_wave_counter(&stats[4], ph_leaf_slots);
+        flush_wave_counter(&stats[5], ph_leaf_lanes);
+        return;
+    }
+#endif
     if (STATS) {
         flush_wave_counter(&stats[SHADOW ? 6 : 0], n_rays);
         flush_wave_counter(&stats[1], 4ull * n_records);
