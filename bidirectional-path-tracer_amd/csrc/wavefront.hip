@@ -144,7 +144,7 @@ BDPT_DEV Rng slot_rng(const GpuCamera& cam, const WfBatch& b, uint32_t slot, uin
 // [record][field][slot in group], so the lanes of a wave that read one field of neighbouring slots read neighbouring
 // words, and everything a slot owns lies within one group (tens of KB).  With the fields of ALL slots in one array each
 // - field rows ns words apart - a kernel that reads several records of a slot touches a different page for every
-// field (k_conn_gen: 3.6 address-translation misses per memory instruction).
+// field (measured on an earlier connection kernel: 3.6 address-translation misses per memory instruction).
 BDPT_DEV VertexStore slot_store(const WfBuffers& wb, uint32_t slot) {
     VertexStore st;
     st.ws = wb.vtx + (uint64_t)(slot / kVtxGroup) * ((uint64_t)kVtxGroup * wb.vtx_words);

@@ -26,7 +26,7 @@ def cases(scenes, full):
     from conftest import composite_scene
     k = 2 if full else 1
     return [
-        ("cornell", scenes.cornell_box(128 * k, 64, 10)),                        # staged in LDS: own-triangle test of k_conn_gen
+        ("cornell", scenes.cornell_box(128 * k, 64, 10)),                        # staged in LDS: own-triangle test of k_connect
         ("coplanar", scenes.coplanar_stack(64 * k, 64, 6)),                      # stacked coincident quads: exact ties
         ("mixed3k", scenes.mixed_materials_3k(80 * k, 64, 8)),
         ("coffee", scenes.coffee_machine_standin(480 * k, 270 * k, 16, 10)),     # boxes resting on boxes: faces in one plane
