@@ -8,8 +8,8 @@ and counts what the shortcuts would have answered differently:
     BDPT_LIB=bidirectional-path-tracer_amd/libbdpt_amd_tiecheck.so python tools/tie_check.py [--full]
 
 Prints one JSON object: per scene the eight counters (capi.Context.TIE_COUNT_NAMES) and the SHA-256 of the rendered frame
-(the frame of the normal build must be the same: tests/test_gpu_tie_check.py compares).  --full: the frame sizes behind the
-figures quoted in DESIGN.md (minutes), otherwise sizes for the test suite (seconds)."""
+(the frame of the normal build must be the same: tests/test_gpu_tie_check.py compares).  --full: twice the frame sizes
+(minutes; what profiles/r03/tie_check_full.json holds), otherwise sizes for the test suite (seconds)."""
 import hashlib
 import importlib
 import json
