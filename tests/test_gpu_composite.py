@@ -308,6 +308,74 @@ def test_scenes_without_fixture_match_the_oracle(ctx, scenes, oracle, which):
     sc.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_random_instanced_boxes_match_the_oracle(ctx, scenes, oracle, seed):
+    """Boxes as instances in a Cornell room with every kind of wrapper the face-bit rules of the host tell apart: only
+    moved (with offsets that are zero on some axes, so that a face of the mesh's box, of the object's box in the world's
+    tree and of the triangle share one plane exactly), only turned (by 0, 90, 180 degrees, where turned faces stay
+    axis-parallel, and by odd angles), both; standing on the floor, on one another, against a wall.  Visibility pairs end
+    on their faces from both sides; frames and answers are the CPU restatement's (src/objects/hittable.h:46-157,
+    src/camera.h:425-438)."""
+    rng = np.random.default_rng(seed)
+    s = scenes.CompositeScene()
+    red, white, green, light = scenes._cornell_walls(s)
+    scenes.add_quad_triangles(s, (213, 554, 227), (130, 0, 0), (0, 0, 105), light)
+    metal = s.add_material(scenes.Material(scenes.METAL, (.8, .85, .88), fuzz=0.05))
+    angles = [0.0, 90.0, 180.0, -90.0, 15.0, -18.0, 33.0, 45.0]
+    for k in range(6):
+        size = rng.integers(40, 140, 3).astype(float)
+        mat = metal if k == 4 else white
+        kind = k % 3                       # 0: moved, 1: turned, 2: both
+        f = s.begin_object()
+        if kind == 1:                      # (a turned-only box is modelled where it stands)
+            a = np.array([rng.integers(60, 400), 0.0 if k < 4 else 120.0, rng.integers(60, 400)], dtype=float)
+            scenes._object_box(s, tuple(a), tuple(a + size), mat)
+            s.end_object(f, flags=scenes.OBJECT_ROTATE_Y, rotate_y_degrees=0.0 if k == 1 else float(angles[int(rng.integers(0, len(angles)))]))
+            continue
+        scenes._object_box(s, (0, 0, 0), tuple(size), mat)
+        off = [float(rng.integers(60, 400)), 0.0, float(rng.integers(60, 400))]
+        if k == 3: off[1] = 0.5                                   # not quite on the floor
+        if k == 5: off = [0.0, 0.0, float(rng.integers(100, 300))]     # against the wall x = 0, on the floor
+        if kind == 0:
+            s.end_object(f, flags=scenes.OBJECT_TRANSLATE, offset=tuple(off))
+        else:
+            s.end_object(f, flags=scenes.OBJECT_ROTATE_Y | scenes.OBJECT_TRANSLATE, rotate_y_degrees=float(angles[int(rng.integers(0, len(angles)))]), offset=tuple(off))
+    s.camera = scenes._cornell_camera(36, 9, 7, "random_boxes.png")
+    osc = oracle.scene(s)
+    sc = ctx.scene(s)
+    assert np.array_equal(sc.dfs_leaves().astype(np.int32), osc.world_leaves())
+    cam = capi.camera_initialize(s.camera)
+    ocam, H, sqrt_spp = oracle.camera_initialize(s.camera)
+    W, depth = s.camera.image_width, s.camera.max_depth
+    ofb, ost, _ = osc.render(ocam, W, sqrt_spp, depth, 5 + seed, (0, 0, W, H))
+    assert_bit_equal(sc.render(cam, seed=5 + seed), ofb, "framebuffer")
+    assert_bit_equal(sc.render(cam, seed=5 + seed, megakernel=True), ofb, "framebuffer, single kernel")
+    # hit points of random rays, then pairs between them: they end ON faces, seen from every side
+    n = 8000
+    o = rng.uniform((-50, -50, -300), (600, 600, 600), (n, 3))
+    tgt = rng.uniform((0, 0, 0), (555, 555, 555), (n, 3))
+    rays = np.concatenate([o, tgt - o, np.full((n, 1), 0.001), np.full((n, 1), np.inf)], axis=1)
+    ohits, _ = osc.trace_closest(rays)
+    hits = sc.trace_closest(rays)
+    assert np.array_equal(hits[:, 0], ohits[:, 0])
+    found = ohits[:, 0] != -1
+    assert_bit_equal(hits[found][:, [1, 4, 5, 6, 7, 8, 9, 10]], ohits[found][:, [1, 4, 5, 6, 7, 8, 9, 10]], "hit records")
+    pts = ohits[found][:, 5:8]
+    m = 20000
+    pairs = np.concatenate([pts[rng.integers(0, len(pts), m)], pts[rng.integers(0, len(pts), m)]], axis=1)
+    want = osc.visible(pairs)
+    assert 0 < want.sum() < m
+    for walker in (capi.WALKER_PIPELINE, capi.WALKER_REFERENCE_TREE):
+        ctx.set_query_walker(walker)
+        try:
+            got = np.asarray(sc.visible(pairs))
+        finally:
+            ctx.set_query_walker(capi.WALKER_PIPELINE)
+        bad = np.flatnonzero(got != want)
+        assert len(bad) == 0, "walker %d: %d of %d pairs differ, first %r" % (walker, len(bad), m, pairs[bad[0]])
+    sc.close()
+
+
 def test_composite_without_objects_equals_plain_scene(ctx, scenes):
     """A composite scene with no object and no texture is the plain triangle soup: the same tables, the same kernels
     (the Cornell box is small enough for the variants that keep the whole scene in LDS), the same bits."""
